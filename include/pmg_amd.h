@@ -1,0 +1,250 @@
+/* pmg_amd.h -- C ABI of the MI355X-native matrix-free p-multigrid hot path.
+ *
+ * One shared library (pmg-dolfinx_amd/lib/libpmg_amd.so, built for gfx950 by
+ * __graft_entry__.build()).  Plain pointers and sizes only; every device
+ * pointer is caller-owned unless stated otherwise and must stay valid for the
+ * lifetime of the handle that was given it (the reference's objects hold
+ * non-owning std::span's of device memory in exactly the same way,
+ * src/laplacian.hpp:500-509).  All functions return 0 on success and a
+ * negative code on failure; pmg_last_error() returns the message of the last
+ * failure on the calling thread (the reference throws std::runtime_error for
+ * the same conditions -- src/laplacian.hpp:346,479, src/vector.hpp:343,
+ * src/cg.hpp:125,138 -- and print+exit(1)s on HIP errors, src/util.hpp:10-18).
+ * Nothing here is thread safe; one host thread per GPU, like the reference.
+ *
+ * The reference's interface for this path is header-only C++ duck typing over
+ * dolfinx types; each entry point below names the reference
+ * member it replaces.  dolfinx's IndexMap/Scatterer inputs are flattened to
+ * arrays.  INTEGRATION.md shows the thin C++ adapter a maintainer would add on
+ * the reference side.
+ *
+ * All citations are relative to Wells-Group/pmg-dolfinx @ 2024_08_07.
+ */
+#ifndef PMG_AMD_H
+#define PMG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMG_OK 0
+#define PMG_ERR_INVALID -1   /* bad argument / unsupported degree / size mismatch */
+#define PMG_ERR_HIP -2       /* a HIP runtime call failed */
+#define PMG_ERR_NUMERIC -3   /* e.g. TQLI did not converge */
+#define PMG_MAX_DEGREE 8
+
+typedef void* pmg_stream; /* hipStream_t (0 = default stream) */
+
+typedef struct pmg_layout_s* pmg_layout;
+typedef struct pmg_laplacian_s* pmg_laplacian;
+typedef struct pmg_chebyshev_s* pmg_chebyshev;
+typedef struct pmg_cg_s* pmg_cg;
+typedef struct pmg_interpolator_s* pmg_interpolator;
+typedef struct pmg_multigrid_s* pmg_multigrid;
+
+const char* pmg_last_error(void);
+int pmg_version(void);
+
+/* ---- host-side tables (no GPU needed) ------------------------------------
+ * What the reference gets from basix at construction time.
+ * pmg_gll_table: n-point Gauss-Lobatto-Legendre rule on [0,1]
+ *   (basix make_quadrature(gll, interval), src/laplacian.hpp:307-309).
+ * pmg_lagrange_derivative_table: D[q*n+i] = l_i'(x_q) on the GLL nodes
+ *   (second half of element1D.tabulate(1,...), src/laplacian.hpp:312-317).
+ * pmg_interpolation_table: M[j*(pc+1)+k] = l^coarse_k(x^fine_j)
+ *   (1-D factor of basix::compute_interpolation_operator, src/interpolate.hpp:118).
+ * pmg_tqli: eigenvalues of a symmetric tridiagonal matrix, in place on d
+ *   (tqli(), src/cg.hpp:55-84). */
+int pmg_gll_table(int n, double* points, double* weights);
+int pmg_lagrange_derivative_table(int n, double* D);
+int pmg_interpolation_table(int p_coarse, int p_fine, double* M);
+int pmg_tqli(double* d, double* e, int n);
+
+/* ---- distributed vector layout -------------------------------------------
+ * Replaces the data members of acc::Vector (src/vector.hpp:83-96,304-324): a
+ * vector is a caller-owned device array of size_local + num_ghosts doubles
+ * (block size 1), described by a layout.  send_indices (owned positions packed
+ * for the neighbours, == Scatterer::local_indices()) and recv_indices (ghost
+ * positions, relative to size_local, == Scatterer::remote_indices()) are device
+ * arrays; send_buffer / recv_buffer are caller-owned device staging buffers of
+ * n_send / n_recv doubles.
+ *
+ * The exchange itself is the caller's (the reference delegates it to
+ * dolfinx::common::Scatterer over MPI, src/vector.hpp:203-206,215): `exchange`
+ * is called with phase 0 after the pack kernel has been enqueued on `stream`
+ * (start moving send_buffer -> the neighbours' recv_buffer, asynchronously with
+ * respect to `stream`), and with phase 1 before the unpack kernel is enqueued
+ * (make `stream` wait for the arrival).  It must return 0.  With no neighbours
+ * (n_send == n_recv == 0) it is never called and may be NULL.
+ *
+ * `allreduce_sum` sums `n` host doubles over all ranks in place (the
+ * reference's MPI_Allreduce, src/vector.hpp:350); NULL on a single rank. */
+typedef int (*pmg_exchange_fn)(void* user, int phase, pmg_stream stream);
+typedef int (*pmg_allreduce_fn)(void* user, double* values, int n);
+
+int pmg_layout_create(pmg_layout* out, int32_t size_local, int32_t num_ghosts, int32_t n_send,
+                      const int32_t* send_indices, double* send_buffer, int32_t n_recv,
+                      const int32_t* recv_indices, double* recv_buffer, pmg_exchange_fn exchange,
+                      pmg_allreduce_fn allreduce_sum, void* user);
+int pmg_layout_destroy(pmg_layout l);
+int32_t pmg_layout_size_local(pmg_layout l);
+int32_t pmg_layout_num_ghosts(pmg_layout l);
+
+/* Vector::scatter_fwd_begin / scatter_fwd_end (src/vector.hpp:186-238): owner ->
+ * ghost update of x; pack/unpack run on `stream` without host synchronisation. */
+int pmg_scatter_fwd_begin(pmg_layout l, const double* x, pmg_stream stream);
+int pmg_scatter_fwd_end(pmg_layout l, double* x, pmg_stream stream);
+/* Vector::scatter_rev_begin / _end (src/vector.hpp:249-286): ghost -> owner,
+ * accumulated into the owned entries.  Not used on the hot path. */
+int pmg_scatter_rev_begin(pmg_layout l, const double* x, pmg_stream stream);
+int pmg_scatter_rev_end(pmg_layout l, double* x, pmg_stream stream);
+
+/* ---- BLAS-1 (free functions of src/vector.hpp:333-454) ---------------------
+ * Ranges follow the reference: set and scale touch owned+ghost entries
+ * (:109-115, :413-418); axpy, copy, pointwise_mult and the reductions touch the
+ * owned entries only (:398-407, :424-431, :438-447, :334-352). */
+int pmg_vec_set(pmg_layout l, double* x, double value, pmg_stream stream);
+int pmg_vec_scale(pmg_layout l, double* x, double alpha, pmg_stream stream);
+int pmg_vec_copy(pmg_layout l, double* dst, const double* src, pmg_stream stream);
+/* r = alpha * x + y */
+int pmg_vec_axpy(pmg_layout l, double* r, double alpha, const double* x, const double* y,
+                 pmg_stream stream);
+/* w = x .* y */
+int pmg_vec_pointwise_mult(pmg_layout l, double* w, const double* x, const double* y,
+                           pmg_stream stream);
+/* Synchronous reductions (block until the value is on the host, then allreduce). */
+int pmg_vec_inner_product(pmg_layout l, const double* a, const double* b, double* result,
+                          pmg_stream stream);
+int pmg_vec_squared_norm(pmg_layout l, const double* a, double* result, pmg_stream stream);
+/* norm_type 0 = l2, 1 = linf (max |a_i|; the reference's abs-after-max slip,
+ * src/vector.hpp:381-382, is not reproduced). */
+int pmg_vec_norm(pmg_layout l, const double* a, int norm_type, double* result, pmg_stream stream);
+
+/* ---- matrix-free Laplacian (acc::MatFreeLaplacian, src/laplacian.hpp:284-526)
+ * Arguments mirror the reference constructor (:289-297); all arrays are device
+ * pointers except the two cell lists, which are host arrays like the
+ * reference's std::vector<int>:
+ *   kappa          [ncells]               DG-0 coefficient per cell
+ *   dofmap         [ncells * (degree+1)^3] local dof of (cell, t), t = a*nd^2+b*nd+c
+ *   xgeom          [3 * npoints]          vertex coordinates
+ *   geom_dofmap    [8 * ncells]           cell vertices, tensor-product order k = i*4+j*2+l
+ *   bc_marker      [size_local+num_ghosts] 1 on Dirichlet dofs
+ *   lcells/bcells  cells that touch no ghost dof / cells that do (+ ghost cells),
+ *                  src/mesh.hpp:105-143
+ * The reference also takes dphi_geometry and G_weights from the caller
+ * (basix tabulations of the trilinear coordinate element and the 3-D GLL
+ * weights); they are fully determined by `degree`, so the library builds them
+ * itself -- pass them to pmg_laplacian_create_with_tables to override.
+ * The constructor precomputes the geometry tensor G for every cell
+ * (geometry_computation, :22-113, with the determinant expanded correctly and G
+ * indexed by cell id -- SURVEY.md quirks Q1, Q2) and its own masked copy of the
+ * dofmap; degrees 1..PMG_MAX_DEGREE are supported (the reference stops at 5,
+ * :335-346). */
+int pmg_laplacian_create(pmg_laplacian* out, pmg_layout layout, int degree, int32_t ncells,
+                         const double* kappa, const int32_t* dofmap, const double* xgeom,
+                         int32_t npoints, const int32_t* geom_dofmap, const int32_t* lcells,
+                         int32_t n_lcells, const int32_t* bcells, int32_t n_bcells,
+                         const int8_t* bc_marker, pmg_stream stream);
+int pmg_laplacian_create_with_tables(pmg_laplacian* out, pmg_layout layout, int degree,
+                                     int32_t ncells, const double* kappa, const int32_t* dofmap,
+                                     const double* xgeom, int32_t npoints,
+                                     const int32_t* geom_dofmap, const double* dphi_geometry,
+                                     const double* G_weights, const int32_t* lcells,
+                                     int32_t n_lcells, const int32_t* bcells, int32_t n_bcells,
+                                     const int8_t* bc_marker, pmg_stream stream);
+int pmg_laplacian_destroy(pmg_laplacian op);
+/* operator()(in, out), :462-482: zeroes `out` (ghosts included), updates the
+ * ghosts of `in` (side effect, as in the reference), interior cells overlap
+ * the halo exchange, then the boundary cells. */
+int pmg_laplacian_apply(pmg_laplacian op, double* in, double* out, pmg_stream stream);
+/* get_diag_inverse / set_diag_inverse, :484-495 (owned+ghost entries). */
+int pmg_laplacian_get_diag_inverse(pmg_laplacian op, double* diag_inv, pmg_stream stream);
+int pmg_laplacian_set_diag_inverse(pmg_laplacian op, const double* diag_inv, pmg_stream stream);
+/* Matrix-free inverse diagonal of the BC-treated operator, stored in the
+ * operator: replaces "assemble a CSR to read its diagonal"
+ * (examples/pmg/main.cpp:274-279, src/csr.hpp:100-110).  BC rows give 1. */
+int pmg_laplacian_compute_diag_inverse(pmg_laplacian op, pmg_stream stream);
+/* The precomputed geometry tensor in the reference's layout [ncells][nq][6]
+ * (:99-111), for parity tests.  `G_out` is a device array. */
+int pmg_laplacian_get_geometry(pmg_laplacian op, double* G_out, pmg_stream stream);
+/* GLL-collocated load vector b_i = sum_cells kappa * w_q * detJ_q * f_i at q = i
+ * (what dolfinx assemble_vector does for L = inner(f, v)*dx with the GLL rule,
+ * examples/pmg/poisson.py:40; examples/pmg/main.cpp:289-295), then set_bc:
+ * b[bc] = 0.  `f` holds the nodal values of the source term. */
+int pmg_laplacian_assemble_rhs(pmg_laplacian op, const double* f, double* b, pmg_stream stream);
+int pmg_laplacian_degree(pmg_laplacian op);
+/* Dominant-kernel timing hook for bench.py: enqueue `reps` launches of the
+ * stiffness kernel over every local cell (no halo, no zero-fill) bracketed by
+ * HIP events on `stream`; returns the mean milliseconds per launch. */
+int pmg_laplacian_time_kernel(pmg_laplacian op, const double* in, double* out, int reps,
+                              double* ms_per_launch, pmg_stream stream);
+
+/* ---- Chebyshev smoother (acc::Chebyshev, src/chebyshev.hpp:19-106) -------- */
+int pmg_chebyshev_create(pmg_chebyshev* out, pmg_layout layout, double eig_min, double eig_max);
+int pmg_chebyshev_destroy(pmg_chebyshev s);
+int pmg_chebyshev_set_max_iterations(pmg_chebyshev s, int max_iter);
+/* solve(A, x, b, verbose), :46-91.  x is in/out. */
+int pmg_chebyshev_solve(pmg_chebyshev s, pmg_laplacian A, double* x, const double* b,
+                        pmg_stream stream);
+
+/* ---- Jacobi-PCG + Lanczos eigenvalue estimate (acc::CGSolver, src/cg.hpp:93-250) */
+int pmg_cg_create(pmg_cg* out, pmg_layout layout);
+int pmg_cg_destroy(pmg_cg s);
+int pmg_cg_set_max_iterations(pmg_cg s, int max_iter);
+int pmg_cg_set_tolerance(pmg_cg s, double rtol);
+int pmg_cg_store_coefficients(pmg_cg s, int flag);
+/* solve(A, x, b), :147-222; *iterations receives the iteration count.  If
+ * `precond` is non-NULL the V-cycle (zero initial guess) replaces the hard-wired
+ * Jacobi preconditioner (not in the reference). */
+int pmg_cg_solve(pmg_cg s, pmg_laplacian A, double* x, const double* b, pmg_multigrid precond,
+                 int* iterations, pmg_stream stream);
+/* alphas()/betas(), :118-119; returns the number stored. */
+int pmg_cg_coefficients(pmg_cg s, double* alphas, double* betas, int capacity);
+/* compute_eigenvalues(), :121-142: sorted ascending; returns the count or <0. */
+int pmg_cg_compute_eigenvalues(pmg_cg s, double* eigs, int capacity);
+int pmg_cg_residual(pmg_cg s, double* rnorm);
+
+/* ---- p-transfer (Interpolator<T>, src/interpolate.hpp:93-329) -------------
+ * Coarse (Q1) and fine (Q2) spaces on the same cells; dofmaps as for the
+ * operator; lcells/bcells as there. */
+int pmg_interpolator_create(pmg_interpolator* out, pmg_layout layout_coarse,
+                            pmg_layout layout_fine, int degree_coarse, int degree_fine,
+                            int32_t ncells, const int32_t* dofmap_coarse,
+                            const int32_t* dofmap_fine, const int32_t* lcells, int32_t n_lcells,
+                            const int32_t* bcells, int32_t n_bcells, pmg_stream stream);
+int pmg_interpolator_destroy(pmg_interpolator ip);
+/* interpolate(Q1_vector, Q2_vector), :186-239: prolongation, updates the ghosts of `coarse`. */
+int pmg_interpolator_interpolate(pmg_interpolator ip, double* coarse, double* fine,
+                                 pmg_stream stream);
+/* reverse_interpolate(Q2_vector, Q1_vector), :246-303: restriction (multiplicity-
+ * weighted transpose), updates the ghosts of `fine`, zeroes `coarse` first. */
+int pmg_interpolator_reverse_interpolate(pmg_interpolator ip, double* fine, double* coarse,
+                                         pmg_stream stream);
+
+/* ---- V-cycle (acc::MultigridPreconditioner, src/pmg.hpp:16-184) -----------
+ * Levels are ordered coarse -> fine like the reference's vectors.  The handle
+ * allocates its own work vectors (:35-41).  coarse solve = smoother[0]
+ * (:106-109; the PETSc/hypre AMG of src/amg.hpp is out of scope). */
+int pmg_multigrid_create(pmg_multigrid* out, int nlevels, const pmg_layout* layouts,
+                         const int8_t* bc_marker_coarsest);
+int pmg_multigrid_destroy(pmg_multigrid mg);
+int pmg_multigrid_set_operators(pmg_multigrid mg, const pmg_laplacian* ops);          /* :48 */
+int pmg_multigrid_set_solvers(pmg_multigrid mg, const pmg_chebyshev* smoothers);      /* :44 */
+int pmg_multigrid_set_interpolators(pmg_multigrid mg, const pmg_interpolator* interp); /* :50-53 */
+/* apply(x = rhs, y = initial guess in / result out, verbose), :56-155.  If
+ * rnorm is non-NULL the final residual norm ||b - A y|| is computed (the
+ * reference prints it when verbose, :147-150) -- this costs one extra apply and a
+ * host synchronisation. */
+int pmg_multigrid_apply(pmg_multigrid mg, const double* rhs, double* y, double* rnorm,
+                        pmg_stream stream);
+/* Number of stiffness-kernel launches issued by the last pmg_multigrid_apply,
+ * per level (coarse -> fine); for the byte accounting in bench.py. */
+int pmg_multigrid_apply_counts(pmg_multigrid mg, int* counts, int capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMG_AMD_H */

@@ -1,0 +1,162 @@
+"""ctypes binding of ``lib/libpmg_amd.so`` (C ABI: ``include/pmg_amd.h``).
+
+The library is the product; there is no Python or CPU fallback.  If it has not
+been built (``python -c 'import __graft_entry__ as g; g.build()'``) every
+attempt to use it raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpmg_amd.so")
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+c_bp = C.POINTER(C.c_int8)
+vp = C.c_void_p
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int, vp)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, c_dp, C.c_int)
+
+
+class PmgError(RuntimeError):
+    """A pmg_* call returned non-zero; the message is ``pmg_last_error()``."""
+
+
+_SIGS = {
+    # name: (restype, argtypes)
+    "pmg_last_error": (C.c_char_p, []),
+    "pmg_version": (C.c_int, []),
+    "pmg_gll_table": (C.c_int, [C.c_int, c_dp, c_dp]),
+    "pmg_lagrange_derivative_table": (C.c_int, [C.c_int, c_dp]),
+    "pmg_interpolation_table": (C.c_int, [C.c_int, C.c_int, c_dp]),
+    "pmg_tqli": (C.c_int, [c_dp, c_dp, C.c_int]),
+    "pmg_layout_create": (
+        C.c_int,
+        [C.POINTER(vp), C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, vp, EXCHANGE_FN, ALLREDUCE_FN, vp],
+    ),
+    "pmg_layout_destroy": (C.c_int, [vp]),
+    "pmg_layout_size_local": (C.c_int32, [vp]),
+    "pmg_layout_num_ghosts": (C.c_int32, [vp]),
+    "pmg_scatter_fwd_begin": (C.c_int, [vp, vp, vp]),
+    "pmg_scatter_fwd_end": (C.c_int, [vp, vp, vp]),
+    "pmg_scatter_rev_begin": (C.c_int, [vp, vp, vp]),
+    "pmg_scatter_rev_end": (C.c_int, [vp, vp, vp]),
+    "pmg_vec_set": (C.c_int, [vp, vp, C.c_double, vp]),
+    "pmg_vec_scale": (C.c_int, [vp, vp, C.c_double, vp]),
+    "pmg_vec_copy": (C.c_int, [vp, vp, vp, vp]),
+    "pmg_vec_axpy": (C.c_int, [vp, vp, C.c_double, vp, vp, vp]),
+    "pmg_vec_pointwise_mult": (C.c_int, [vp, vp, vp, vp, vp]),
+    "pmg_vec_inner_product": (C.c_int, [vp, vp, vp, c_dp, vp]),
+    "pmg_vec_squared_norm": (C.c_int, [vp, vp, c_dp, vp]),
+    "pmg_vec_norm": (C.c_int, [vp, vp, C.c_int, c_dp, vp]),
+    "pmg_laplacian_create": (
+        C.c_int,
+        [C.POINTER(vp), vp, C.c_int, C.c_int32, vp, vp, vp, C.c_int32, vp, c_ip, C.c_int32, c_ip, C.c_int32, vp, vp],
+    ),
+    "pmg_laplacian_create_with_tables": (
+        C.c_int,
+        [C.POINTER(vp), vp, C.c_int, C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp, c_ip, C.c_int32, c_ip,
+         C.c_int32, vp, vp],
+    ),
+    "pmg_laplacian_destroy": (C.c_int, [vp]),
+    "pmg_laplacian_apply": (C.c_int, [vp, vp, vp, vp]),
+    "pmg_laplacian_get_diag_inverse": (C.c_int, [vp, vp, vp]),
+    "pmg_laplacian_set_diag_inverse": (C.c_int, [vp, vp, vp]),
+    "pmg_laplacian_compute_diag_inverse": (C.c_int, [vp, vp]),
+    "pmg_laplacian_get_geometry": (C.c_int, [vp, vp, vp]),
+    "pmg_laplacian_assemble_rhs": (C.c_int, [vp, vp, vp, vp]),
+    "pmg_laplacian_degree": (C.c_int, [vp]),
+    "pmg_laplacian_time_kernel": (C.c_int, [vp, vp, vp, C.c_int, c_dp, vp]),
+    "pmg_chebyshev_create": (C.c_int, [C.POINTER(vp), vp, C.c_double, C.c_double]),
+    "pmg_chebyshev_destroy": (C.c_int, [vp]),
+    "pmg_chebyshev_set_max_iterations": (C.c_int, [vp, C.c_int]),
+    "pmg_chebyshev_solve": (C.c_int, [vp, vp, vp, vp, vp]),
+    "pmg_cg_create": (C.c_int, [C.POINTER(vp), vp]),
+    "pmg_cg_destroy": (C.c_int, [vp]),
+    "pmg_cg_set_max_iterations": (C.c_int, [vp, C.c_int]),
+    "pmg_cg_set_tolerance": (C.c_int, [vp, C.c_double]),
+    "pmg_cg_store_coefficients": (C.c_int, [vp, C.c_int]),
+    "pmg_cg_solve": (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]),
+    "pmg_cg_coefficients": (C.c_int, [vp, c_dp, c_dp, C.c_int]),
+    "pmg_cg_compute_eigenvalues": (C.c_int, [vp, c_dp, C.c_int]),
+    "pmg_cg_residual": (C.c_int, [vp, c_dp]),
+    "pmg_interpolator_create": (
+        C.c_int,
+        [C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int32, vp, vp, c_ip, C.c_int32, c_ip, C.c_int32, vp],
+    ),
+    "pmg_interpolator_destroy": (C.c_int, [vp]),
+    "pmg_interpolator_interpolate": (C.c_int, [vp, vp, vp, vp]),
+    "pmg_interpolator_reverse_interpolate": (C.c_int, [vp, vp, vp, vp]),
+    "pmg_multigrid_create": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp), vp]),
+    "pmg_multigrid_destroy": (C.c_int, [vp]),
+    "pmg_multigrid_set_operators": (C.c_int, [vp, C.POINTER(vp)]),
+    "pmg_multigrid_set_solvers": (C.c_int, [vp, C.POINTER(vp)]),
+    "pmg_multigrid_set_interpolators": (C.c_int, [vp, C.POINTER(vp)]),
+    "pmg_multigrid_apply": (C.c_int, [vp, vp, vp, c_dp, vp]),
+    "pmg_multigrid_apply_counts": (C.c_int, [vp, C.POINTER(C.c_int), C.c_int]),
+}
+
+# functions whose int return value is a count, not a status
+_COUNT_FUNCS = {"pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
+                "pmg_laplacian_degree"}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names ``include/pmg_amd.h`` declares (kept in sync by tests/test_abi.py)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP library has not been built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root. "
+                "There is no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().pmg_last_error().decode("utf-8", "replace")
+        raise PmgError(f"{what}: {msg} (code {rc})" if what else f"{msg} (code {rc})")
+
+
+def call(name: str, *args):
+    """Call a status-returning entry point and raise ``PmgError`` on failure."""
+    rc = getattr(lib(), name)(*args)
+    if name in _COUNT_FUNCS:
+        if rc < 0:
+            check(rc, name)
+        return rc
+    check(rc, name)
+    return rc
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / numpy array, as c_void_p."""
+    if t is None:
+        return vp(0)
+    if hasattr(t, "data_ptr"):
+        return vp(t.data_ptr())
+    return vp(t.ctypes.data)
+
+
+def current_stream():
+    """hipStream_t of torch's current stream on the current device."""
+    import torch
+
+    return vp(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,95 @@
+// Shared definitions of the pmg_amd library (gfx950 only).
+#pragma once
+
+#include "../../include/pmg_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace pmg
+{
+extern thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...);
+
+#define PMG_HIP(call)                                                                              \
+  do                                                                                               \
+  {                                                                                                \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return pmg::fail(PMG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),         \
+                       __FILE__, __LINE__);                                                        \
+  } while (0)
+
+#define PMG_TRY(call)                                                                              \
+  do                                                                                               \
+  {                                                                                                \
+    int rc_ = (call);                                                                              \
+    if (rc_ != PMG_OK)                                                                             \
+      return rc_;                                                                                  \
+  } while (0)
+
+#define PMG_REQUIRE(cond, ...)                                                                     \
+  do                                                                                               \
+  {                                                                                                \
+    if (!(cond))                                                                                   \
+      return pmg::fail(PMG_ERR_INVALID, __VA_ARGS__);                                              \
+  } while (0)
+
+inline hipStream_t S(pmg_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int MAXND = PMG_MAX_DEGREE + 1;
+
+// 1-D tables on the host (tables.cpp)
+void gll_table(int n, double* x, double* w);
+void lagrange_derivative_table(int n, const double* x, double* D);
+void lagrange_eval_table(int nc, const double* xc, int nf, const double* xf, double* M);
+
+// Kernel-argument copy of a small dense table (<= 9x9), passed by value.
+struct Table
+{
+  double v[MAXND * MAXND];
+};
+} // namespace pmg
+
+struct pmg_layout_s
+{
+  int32_t size_local = 0, num_ghosts = 0, n_send = 0, n_recv = 0;
+  const int32_t* send_idx = nullptr;
+  const int32_t* recv_idx = nullptr;
+  double* send_buf = nullptr;
+  double* recv_buf = nullptr;
+  pmg_exchange_fn exchange = nullptr;
+  pmg_allreduce_fn allreduce = nullptr;
+  void* user = nullptr;
+  // reduction scratch (owned)
+  double* d_partials = nullptr; // [2 * RED_BLOCKS]
+  double* h_result = nullptr;   // pinned, [4]
+  int32_t total() const { return size_local + num_ghosts; }
+};
+
+namespace pmg
+{
+constexpr int RED_BLOCKS = 1024;
+constexpr int RED_THREADS = 256;
+
+// vector.hip -- stream-ordered building blocks used by the solvers
+int dot_async(pmg_layout l, const double* a, const double* b, double* d_out, hipStream_t s);
+int dot_host(pmg_layout l, const double* a, const double* b, double* result, hipStream_t s);
+void launch_axpy(int n, double* r, double alpha, const double* x, const double* y, hipStream_t s);
+void launch_pointwise(int n, double* w, const double* x, const double* y, hipStream_t s);
+// Chebyshev fused passes (src/chebyshev.hpp:57-83)
+void launch_cheb_init(int n, double* r, double* z, const double* b, const double* q,
+                      const double* dinv, double c0, hipStream_t s);
+void launch_cheb_step(int n, double* x, double* r, double* z, const double* q, const double* dinv,
+                      double c1, double c2, hipStream_t s);
+void launch_add(int n, double* x, const double* z, hipStream_t s);
+void launch_mask_bc(int n, double* b, const int8_t* bc, hipStream_t s);
+// CG fused passes (src/cg.hpp:160-211)
+void launch_cg_update(int n, double* x, double* r, double* y, const double* p, const double* dinv,
+                      double alpha, hipStream_t s);
+} // namespace pmg

@@ -1,0 +1,457 @@
+// Solver layer: 4th-kind Chebyshev smoother, Jacobi-PCG with Lanczos eigenvalue
+// estimate, p-multigrid V-cycle.  Replaces src/chebyshev.hpp, src/cg.hpp and
+// src/pmg.hpp.  Everything is enqueued on the caller's stream; the only host
+// synchronisations are the CG dot products (their values steer the iteration,
+// src/cg.hpp:182,195,206) and an optional residual norm of the V-cycle.
+//
+// The smoother issues one fused vector pass per Chebyshev step (x += z; r -= q;
+// z = c1 z + c2 D^-1 r : 5 reads + 3 writes per dof) where the reference issues
+// 5 Thrust launches (src/chebyshev.hpp:73-83), and the V-cycle drops the residual
+// recomputations that only feed log lines (src/pmg.hpp:76-89,114-117,132-143):
+// the residual a pre-smooth leaves in its recurrence IS b - A u (:86-87), and the
+// last A z of a post-smooth changes neither x nor anything that is read again.
+#include "common.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+using namespace pmg;
+
+namespace pmg
+{
+int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s);
+const double* laplacian_diag_inv(pmg_laplacian op);
+pmg_layout laplacian_layout(pmg_laplacian op);
+long long laplacian_launches(pmg_laplacian op);
+int interp_prolong(pmg_interpolator ip, double* coarse, double* fine, hipStream_t s);
+int interp_restrict(pmg_interpolator ip, double* fine, double* coarse, hipStream_t s);
+void launch_cheb_first(int n, double* x, double* r, double* z, const double* q, const double* dinv,
+                       double c1, double c2, hipStream_t s);
+} // namespace pmg
+
+struct pmg_chebyshev_s
+{
+  pmg_layout layout = nullptr;
+  double eig_min = 0, eig_max = 1;
+  int max_iter = 1;
+  double *r = nullptr, *z = nullptr, *q = nullptr; // work vectors (src/chebyshev.hpp:28-32)
+};
+
+struct pmg_cg_s
+{
+  pmg_layout layout = nullptr;
+  int max_iter = 0;
+  double rtol = 0;
+  bool store = false;
+  double *r = nullptr, *y = nullptr, *p = nullptr; // src/cg.hpp:101-104
+  std::vector<double> alphas, betas, residuals;
+};
+
+struct pmg_multigrid_s
+{
+  int L = 0;
+  std::vector<pmg_layout> layouts;
+  const int8_t* bc0 = nullptr;
+  std::vector<pmg_laplacian> ops;
+  std::vector<pmg_chebyshev> smoothers;
+  std::vector<pmg_interpolator> interps;
+  std::vector<double*> u, b; // per level (finest level uses the caller's vectors)
+  std::vector<int> counts;
+};
+
+namespace
+{
+int alloc_vec(pmg_layout l, double** p)
+{
+  size_t n = l->total() ? l->total() : 1;
+  PMG_HIP(hipMalloc(p, sizeof(double) * n));
+  PMG_HIP(hipMemset(*p, 0, sizeof(double) * n));
+  return PMG_OK;
+}
+
+// src/chebyshev.hpp:46-91.
+//   need_r : keep r = b - A x current on exit (costs the loop's last apply)
+//   x_zero : x is known to be 0 on entry (A 0 = 0, so r = b and x := z)
+int cheb_solve(pmg_chebyshev sm, pmg_laplacian A, double* x, const double* b, bool need_r,
+               bool x_zero, hipStream_t s)
+{
+  pmg_layout l = sm->layout;
+  PMG_REQUIRE(laplacian_layout(A) == l, "Chebyshev: operator and smoother layouts differ");
+  const int n = l->size_local;
+  const double lmax = sm->eig_max; // eig_range[0] is unused, src/chebyshev.hpp:51
+  const double* dinv = laplacian_diag_inv(A); // no per-call D2D copy (:53)
+  const double c0 = 4.0 / (3.0 * lmax);
+  if (x_zero)
+    launch_cheb_init(n, sm->r, sm->z, b, nullptr, dinv, c0, s);
+  else
+  {
+    PMG_TRY(laplacian_apply(A, x, sm->q, s));               // :56
+    launch_cheb_init(n, sm->r, sm->z, b, sm->q, dinv, c0, s); // :57,67-68
+  }
+  for (int i = 1; i <= sm->max_iter; ++i)
+  {
+    const bool last = (i == sm->max_iter);
+    if (last && !need_r)
+    {
+      if (x_zero && i == 1)
+        PMG_HIP(hipMemcpyAsync(x, sm->z, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+      else
+        launch_add(n, x, sm->z, s); // :73
+      break;
+    }
+    PMG_TRY(laplacian_apply(A, sm->z, sm->q, s)); // :76
+    const double c1 = (2.0 * i - 1.0) / (2.0 * i + 3.0);
+    const double c2 = (8.0 * i + 4.0) / (2.0 * i + 3.0) / lmax;
+    if (x_zero && i == 1)
+      launch_cheb_first(n, x, sm->r, sm->z, sm->q, dinv, c1, c2, s);
+    else
+      launch_cheb_step(n, x, sm->r, sm->z, sm->q, dinv, c1, c2, s); // :73,77,80-83
+  }
+  if (sm->max_iter == 0 && x_zero)
+    PMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * n, s));
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+// src/pmg.hpp:56-155 (lean form, see the file header)
+int mg_apply(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStream_t s)
+{
+  const int L = mg->L;
+  PMG_REQUIRE((int)mg->ops.size() == L && (int)mg->smoothers.size() == L
+                  && (int)mg->interps.size() == L - 1,
+              "MultigridPreconditioner: operators / solvers / interpolators not set");
+  std::vector<long long> before(L);
+  for (int i = 0; i < L; ++i)
+    before[i] = laplacian_launches(mg->ops[i]);
+  // u[L-1] = y, b[L-1] = rhs (:65,68) -- used in place; u[i<L-1] = 0 (:63-64) is
+  // folded into the smoothers' x_zero path.
+  mg->u[L - 1] = y;
+  for (int i = L - 1; i > 0; --i)
+  {
+    const double* bi = (i == L - 1) ? rhs : mg->b[i];
+    const bool zero = (i == L - 1) ? y_zero : true;
+    PMG_TRY(cheb_solve(mg->smoothers[i], mg->ops[i], mg->u[i], bi, true, zero, s)); // :83-87
+    PMG_TRY(interp_restrict(mg->interps[i - 1], mg->smoothers[i]->r, mg->b[i - 1], s)); // :92
+  }
+  if (L > 1)
+    launch_mask_bc(mg->layouts[0]->size_local, mg->b[0], mg->bc0, s); // :100-103
+  {
+    const double* b0 = (L == 1) ? rhs : mg->b[0];
+    const bool zero = (L == 1) ? y_zero : true;
+    PMG_TRY(cheb_solve(mg->smoothers[0], mg->ops[0], mg->u[0], b0, false, zero, s)); // :109
+  }
+  for (int i = 0; i < L - 1; ++i)
+  {
+    double* du = mg->smoothers[i + 1]->q;                              // work vector as du
+    PMG_TRY(interp_prolong(mg->interps[i], mg->u[i], du, s));          // :123
+    launch_add(mg->layouts[i + 1]->size_local, mg->u[i + 1], du, s);   // :129
+    const double* bi = (i + 1 == L - 1) ? rhs : mg->b[i + 1];
+    PMG_TRY(cheb_solve(mg->smoothers[i + 1], mg->ops[i + 1], mg->u[i + 1], bi, false, false, s)); // :138
+  }
+  for (int i = 0; i < L; ++i)
+    mg->counts[i] = (int)(laplacian_launches(mg->ops[i]) - before[i]);
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+} // namespace
+
+// ------------------------------------------------------------- Chebyshev --
+extern "C" int pmg_chebyshev_create(pmg_chebyshev* out, pmg_layout layout, double eig_min,
+                                    double eig_max)
+{
+  PMG_REQUIRE(out && layout, "pmg_chebyshev_create: NULL argument");
+  PMG_REQUIRE(eig_max > 0.0, "pmg_chebyshev_create: eig_max must be positive");
+  auto* sm = new pmg_chebyshev_s;
+  sm->layout = layout;
+  sm->eig_min = eig_min;
+  sm->eig_max = eig_max;
+  PMG_TRY(alloc_vec(layout, &sm->r));
+  PMG_TRY(alloc_vec(layout, &sm->z));
+  PMG_TRY(alloc_vec(layout, &sm->q));
+  *out = sm;
+  return PMG_OK;
+}
+
+extern "C" int pmg_chebyshev_destroy(pmg_chebyshev sm)
+{
+  if (!sm)
+    return PMG_OK;
+  (void)hipFree(sm->r);
+  (void)hipFree(sm->z);
+  (void)hipFree(sm->q);
+  delete sm;
+  return PMG_OK;
+}
+
+extern "C" int pmg_chebyshev_set_max_iterations(pmg_chebyshev sm, int max_iter)
+{
+  PMG_REQUIRE(sm && max_iter >= 0, "pmg_chebyshev_set_max_iterations: bad argument");
+  sm->max_iter = max_iter;
+  return PMG_OK;
+}
+
+extern "C" int pmg_chebyshev_solve(pmg_chebyshev sm, pmg_laplacian A, double* x, const double* b,
+                                   pmg_stream stream)
+{
+  PMG_REQUIRE(sm && A && x && b, "pmg_chebyshev_solve: NULL argument");
+  return cheb_solve(sm, A, x, b, false, false, S(stream));
+}
+
+// -------------------------------------------------------------------- CG --
+extern "C" int pmg_cg_create(pmg_cg* out, pmg_layout layout)
+{
+  PMG_REQUIRE(out && layout, "pmg_cg_create: NULL argument");
+  auto* cg = new pmg_cg_s;
+  cg->layout = layout;
+  PMG_TRY(alloc_vec(layout, &cg->r));
+  PMG_TRY(alloc_vec(layout, &cg->y));
+  PMG_TRY(alloc_vec(layout, &cg->p));
+  *out = cg;
+  return PMG_OK;
+}
+
+extern "C" int pmg_cg_destroy(pmg_cg cg)
+{
+  if (!cg)
+    return PMG_OK;
+  (void)hipFree(cg->r);
+  (void)hipFree(cg->y);
+  (void)hipFree(cg->p);
+  delete cg;
+  return PMG_OK;
+}
+
+extern "C" int pmg_cg_set_max_iterations(pmg_cg cg, int max_iter)
+{
+  PMG_REQUIRE(cg && max_iter >= 0, "pmg_cg_set_max_iterations: bad argument");
+  cg->max_iter = max_iter; // src/cg.hpp:107-113
+  cg->alphas.reserve(max_iter);
+  cg->betas.reserve(max_iter);
+  cg->residuals.reserve(max_iter);
+  return PMG_OK;
+}
+
+extern "C" int pmg_cg_set_tolerance(pmg_cg cg, double rtol)
+{
+  PMG_REQUIRE(cg, "pmg_cg_set_tolerance: NULL argument");
+  cg->rtol = rtol;
+  return PMG_OK;
+}
+
+extern "C" int pmg_cg_store_coefficients(pmg_cg cg, int flag)
+{
+  PMG_REQUIRE(cg, "pmg_cg_store_coefficients: NULL argument");
+  cg->store = flag != 0;
+  return PMG_OK;
+}
+
+// src/cg.hpp:147-222
+extern "C" int pmg_cg_solve(pmg_cg cg, pmg_laplacian A, double* x, const double* b,
+                            pmg_multigrid precond, int* iterations, pmg_stream stream)
+{
+  PMG_REQUIRE(cg && A && x && b, "pmg_cg_solve: NULL argument");
+  pmg_layout l = cg->layout;
+  PMG_REQUIRE(laplacian_layout(A) == l, "pmg_cg_solve: operator and solver layouts differ");
+  hipStream_t s = S(stream);
+  const int n = l->size_local;
+  const double* dinv = laplacian_diag_inv(A); // :154
+  double *r = cg->r, *y = cg->y, *p = cg->p;
+
+  auto precondition = [&](double* out_z, const double* in_r) -> int
+  {
+    if (precond)
+    {
+      PMG_HIP(hipMemsetAsync(out_z, 0, sizeof(double) * l->total(), s));
+      return mg_apply(precond, in_r, out_z, true, s);
+    }
+    launch_pointwise(n, out_z, in_r, dinv, s); // :161,192
+    return PMG_OK;
+  };
+
+  PMG_TRY(laplacian_apply(A, x, y, s)); // :159
+  launch_axpy(n, r, -1.0, y, b, s);     // :160
+  PMG_TRY(precondition(p, r));          // :161
+  double rnorm0;
+  PMG_TRY(dot_host(l, p, r, &rnorm0, s)); // :163
+  double rnorm = rnorm0;
+  const double rtol2 = cg->rtol * cg->rtol;
+  int k = 0;
+  while (k < cg->max_iter)
+  {
+    ++k;
+    PMG_TRY(laplacian_apply(A, p, y, s)); // :179
+    double py;
+    PMG_TRY(dot_host(l, p, y, &py, s));
+    const double alpha = rnorm / py; // :182
+    if (precond)
+    {
+      launch_axpy(n, x, alpha, p, x, s);  // :186
+      launch_axpy(n, r, -alpha, y, r, s); // :189
+      PMG_TRY(precondition(y, r));
+    }
+    else
+      launch_cg_update(n, x, r, y, p, dinv, alpha, s); // :186-192 fused
+    double rnorm_new;
+    PMG_TRY(dot_host(l, r, y, &rnorm_new, s)); // :195
+    const double beta = rnorm_new / rnorm;
+    rnorm = rnorm_new;
+    if (rnorm / rnorm0 < rtol2) // :206
+      break;
+    launch_axpy(n, p, beta, p, y, s); // :211
+    if (cg->store)                    // :213-218
+    {
+      cg->alphas.push_back(alpha);
+      cg->betas.push_back(beta);
+      cg->residuals.push_back(rnorm);
+    }
+  }
+  if (!cg->store)
+  {
+    cg->residuals.clear();
+    cg->residuals.push_back(rnorm);
+  }
+  if (iterations)
+    *iterations = k;
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+extern "C" int pmg_cg_coefficients(pmg_cg cg, double* alphas, double* betas, int capacity)
+{
+  PMG_REQUIRE(cg, "pmg_cg_coefficients: NULL argument");
+  int n = (int)cg->alphas.size();
+  for (int i = 0; i < n && i < capacity; ++i)
+  {
+    if (alphas)
+      alphas[i] = cg->alphas[i];
+    if (betas)
+      betas[i] = cg->betas[i];
+  }
+  return n;
+}
+
+// src/cg.hpp:121-142
+extern "C" int pmg_cg_compute_eigenvalues(pmg_cg cg, double* eigs, int capacity)
+{
+  PMG_REQUIRE(cg && eigs, "pmg_cg_compute_eigenvalues: NULL argument");
+  const int ne = (int)cg->alphas.size();
+  if (ne < 2)
+    return fail(PMG_ERR_INVALID, "Insufficient data to compute eigenvalues"); // :125
+  PMG_REQUIRE(capacity >= ne, "pmg_cg_compute_eigenvalues: capacity %d < %d", capacity, ne);
+  std::vector<double> d(ne, 0.0), e(ne, 0.0);
+  for (int i = 0; i < ne; ++i)
+    d[i] = 1.0 / cg->alphas[i];
+  for (int i = 0; i < ne - 1; ++i)
+  {
+    d[i + 1] += cg->betas[i] / cg->alphas[i];
+    e[i] = std::sqrt(cg->betas[i]) / cg->alphas[i];
+  }
+  if (pmg_tqli(d.data(), e.data(), ne) != PMG_OK)
+    return fail(PMG_ERR_NUMERIC, "Eigenvalue estimate failed"); // :138
+  std::sort(d.begin(), d.end());
+  for (int i = 0; i < ne; ++i)
+    eigs[i] = d[i];
+  return ne;
+}
+
+extern "C" int pmg_cg_residual(pmg_cg cg, double* rnorm)
+{
+  PMG_REQUIRE(cg && rnorm, "pmg_cg_residual: NULL argument");
+  PMG_REQUIRE(!cg->residuals.empty(), "pmg_cg_residual: no residual recorded");
+  *rnorm = cg->residuals.back(); // src/cg.hpp:144
+  return PMG_OK;
+}
+
+// -------------------------------------------------------------- multigrid --
+extern "C" int pmg_multigrid_create(pmg_multigrid* out, int nlevels, const pmg_layout* layouts,
+                                    const int8_t* bc_marker_coarsest)
+{
+  PMG_REQUIRE(out && layouts && nlevels >= 1, "pmg_multigrid_create: bad argument");
+  PMG_REQUIRE(bc_marker_coarsest, "pmg_multigrid_create: NULL bc marker");
+  auto* mg = new pmg_multigrid_s;
+  mg->L = nlevels;
+  mg->layouts.assign(layouts, layouts + nlevels);
+  mg->bc0 = bc_marker_coarsest;
+  mg->u.assign(nlevels, nullptr);
+  mg->b.assign(nlevels, nullptr);
+  mg->counts.assign(nlevels, 0);
+  for (int i = 0; i < nlevels - 1; ++i) // src/pmg.hpp:35-41 (finest level: caller's vectors)
+  {
+    PMG_TRY(alloc_vec(layouts[i], &mg->u[i]));
+    PMG_TRY(alloc_vec(layouts[i], &mg->b[i]));
+  }
+  *out = mg;
+  return PMG_OK;
+}
+
+extern "C" int pmg_multigrid_destroy(pmg_multigrid mg)
+{
+  if (!mg)
+    return PMG_OK;
+  for (int i = 0; i < mg->L - 1; ++i)
+  {
+    (void)hipFree(mg->u[i]);
+    (void)hipFree(mg->b[i]);
+  }
+  delete mg;
+  return PMG_OK;
+}
+
+extern "C" int pmg_multigrid_set_operators(pmg_multigrid mg, const pmg_laplacian* ops)
+{
+  PMG_REQUIRE(mg && ops, "pmg_multigrid_set_operators: NULL argument");
+  for (int i = 0; i < mg->L; ++i)
+    PMG_REQUIRE(ops[i] && laplacian_layout(ops[i]) == mg->layouts[i],
+                "pmg_multigrid_set_operators: level %d layout mismatch", i);
+  mg->ops.assign(ops, ops + mg->L);
+  return PMG_OK;
+}
+
+extern "C" int pmg_multigrid_set_solvers(pmg_multigrid mg, const pmg_chebyshev* smoothers)
+{
+  PMG_REQUIRE(mg && smoothers, "pmg_multigrid_set_solvers: NULL argument");
+  for (int i = 0; i < mg->L; ++i)
+    PMG_REQUIRE(smoothers[i] && smoothers[i]->layout == mg->layouts[i],
+                "pmg_multigrid_set_solvers: level %d layout mismatch", i);
+  mg->smoothers.assign(smoothers, smoothers + mg->L);
+  return PMG_OK;
+}
+
+extern "C" int pmg_multigrid_set_interpolators(pmg_multigrid mg, const pmg_interpolator* interp)
+{
+  PMG_REQUIRE(mg && (interp || mg->L == 1), "pmg_multigrid_set_interpolators: NULL argument");
+  mg->interps.clear();
+  for (int i = 0; i < mg->L - 1; ++i)
+  {
+    PMG_REQUIRE(interp[i], "pmg_multigrid_set_interpolators: level %d is NULL", i);
+    mg->interps.push_back(interp[i]);
+  }
+  return PMG_OK;
+}
+
+extern "C" int pmg_multigrid_apply(pmg_multigrid mg, const double* rhs, double* y, double* rnorm,
+                                   pmg_stream stream)
+{
+  PMG_REQUIRE(mg && rhs && y, "pmg_multigrid_apply: NULL argument");
+  hipStream_t s = S(stream);
+  PMG_TRY(mg_apply(mg, rhs, y, false, s));
+  if (rnorm) // src/pmg.hpp:141-150
+  {
+    const int L = mg->L;
+    pmg_chebyshev sm = mg->smoothers[L - 1];
+    PMG_TRY(laplacian_apply(mg->ops[L - 1], y, sm->q, s));
+    launch_axpy(mg->layouts[L - 1]->size_local, sm->r, -1.0, sm->q, rhs, s);
+    double v;
+    PMG_TRY(dot_host(mg->layouts[L - 1], sm->r, sm->r, &v, s));
+    *rnorm = std::sqrt(v);
+  }
+  return PMG_OK;
+}
+
+extern "C" int pmg_multigrid_apply_counts(pmg_multigrid mg, int* counts, int capacity)
+{
+  PMG_REQUIRE(mg && counts, "pmg_multigrid_apply_counts: NULL argument");
+  for (int i = 0; i < mg->L && i < capacity; ++i)
+    counts[i] = mg->counts[i];
+  return mg->L;
+}

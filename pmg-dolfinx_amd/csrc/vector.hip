@@ -1,0 +1,629 @@
+// Distributed-vector layer: layout handle, halo pack/unpack, BLAS-1 and the
+// fused smoother / CG passes.  Replaces acc::Vector and the free functions of
+// src/vector.hpp (pack/unpack :24-55, scatter :186-286, BLAS-1 :333-454).
+//
+// Every kernel is a pure HBM stream: 16 B per lane (double2) when the operands
+// are 16-byte aligned, grid capped at 8 blocks per CU and grid-strided.
+// Nothing synchronises the host except the reductions that must return a value.
+#include "common.hpp"
+
+using namespace pmg;
+
+namespace
+{
+constexpr int EW_THREADS = 256;
+constexpr int EW_MAX_BLOCKS = 256 * 8;
+
+inline int ew_blocks(long long work)
+{
+  long long b = (work + EW_THREADS - 1) / EW_THREADS;
+  if (b < 1)
+    b = 1;
+  return (int)(b > EW_MAX_BLOCKS ? EW_MAX_BLOCKS : b);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- halo ----
+__global__ void pack_kernel(int n, const int32_t* __restrict__ idx, const double* __restrict__ in,
+                            double* __restrict__ out)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[i] = in[idx[i]];
+}
+
+__global__ void unpack_kernel(int n, const int32_t* __restrict__ idx, const double* __restrict__ in,
+                              double* __restrict__ out)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[idx[i]] = in[i];
+}
+
+__global__ void unpack_add_kernel(int n, const int32_t* __restrict__ idx,
+                                  const double* __restrict__ in, double* __restrict__ out)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    atomicAdd(&out[idx[i]], in[i]);
+}
+
+// ---- generic element-wise launcher: F::apply(i, args...) on doubles ----
+template <typename F>
+__global__ void ew_kernel2(int n2, F f)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += gridDim.x * blockDim.x)
+    f.pair(i);
+}
+template <typename F>
+__global__ void ew_kernel1(int begin, int n, F f)
+{
+  for (int i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    f.one(i);
+}
+
+template <typename F>
+void ew_launch(int n, bool vec_ok, F f, hipStream_t s)
+{
+  if (n <= 0)
+    return;
+  if (vec_ok)
+  {
+    int n2 = n / 2;
+    if (n2 > 0)
+      ew_kernel2<<<ew_blocks(n2), EW_THREADS, 0, s>>>(n2, f);
+    if (n & 1)
+      ew_kernel1<<<1, 64, 0, s>>>(n - 1, n, f);
+  }
+  else
+    ew_kernel1<<<ew_blocks(n), EW_THREADS, 0, s>>>(0, n, f);
+}
+
+#define D2(p) reinterpret_cast<double2*>(p)
+#define CD2(p) reinterpret_cast<const double2*>(p)
+
+struct SetF
+{
+  double* x;
+  double v;
+  __device__ void pair(int i) const { D2(x)[i] = make_double2(v, v); }
+  __device__ void one(int i) const { x[i] = v; }
+};
+struct ScaleF
+{
+  double* x;
+  double a;
+  __device__ void pair(int i) const
+  {
+    double2 t = D2(x)[i];
+    t.x *= a;
+    t.y *= a;
+    D2(x)[i] = t;
+  }
+  __device__ void one(int i) const { x[i] *= a; }
+};
+struct CopyF
+{
+  double* d;
+  const double* s;
+  __device__ void pair(int i) const { D2(d)[i] = CD2(s)[i]; }
+  __device__ void one(int i) const { d[i] = s[i]; }
+};
+struct AxpyF
+{ // r = a x + y   (src/vector.hpp:398-407)
+  double* r;
+  double a;
+  const double* x;
+  const double* y;
+  __device__ void pair(int i) const
+  {
+    double2 vx = CD2(x)[i], vy = CD2(y)[i];
+    D2(r)[i] = make_double2(vx.x * a + vy.x, vx.y * a + vy.y);
+  }
+  __device__ void one(int i) const { r[i] = x[i] * a + y[i]; }
+};
+struct MulF
+{ // w = x .* y  (src/vector.hpp:438-447)
+  double* w;
+  const double* x;
+  const double* y;
+  __device__ void pair(int i) const
+  {
+    double2 vx = CD2(x)[i], vy = CD2(y)[i];
+    D2(w)[i] = make_double2(vx.x * vy.x, vx.y * vy.y);
+  }
+  __device__ void one(int i) const { w[i] = x[i] * y[i]; }
+};
+struct ChebInitF
+{ // r = b - q ; z = c0 * dinv * r   (src/chebyshev.hpp:57,67-68); q == nullptr: r = b
+  double* r;
+  double* z;
+  const double* b;
+  const double* q;
+  const double* dinv;
+  double c0;
+  __device__ void pair(int i) const
+  {
+    double2 vb = CD2(b)[i], vd = CD2(dinv)[i];
+    double2 vr = vb;
+    if (q)
+    {
+      double2 vq = CD2(q)[i];
+      vr.x -= vq.x;
+      vr.y -= vq.y;
+    }
+    D2(r)[i] = vr;
+    D2(z)[i] = make_double2(c0 * vd.x * vr.x, c0 * vd.y * vr.y);
+  }
+  __device__ void one(int i) const
+  {
+    double vr = b[i] - (q ? q[i] : 0.0);
+    r[i] = vr;
+    z[i] = c0 * dinv[i] * vr;
+  }
+};
+struct ChebStepF
+{ // x += z ; r -= q ; z = c1 z + c2 dinv r   (src/chebyshev.hpp:73-83)
+  double* x;
+  double* r;
+  double* z;
+  const double* q;
+  const double* dinv;
+  double c1, c2;
+  __device__ void pair(int i) const
+  {
+    double2 vx = D2(x)[i], vr = D2(r)[i], vz = D2(z)[i];
+    double2 vq = CD2(q)[i], vd = CD2(dinv)[i];
+    vx.x += vz.x;
+    vx.y += vz.y;
+    vr.x -= vq.x;
+    vr.y -= vq.y;
+    vz.x = c1 * vz.x + c2 * vd.x * vr.x;
+    vz.y = c1 * vz.y + c2 * vd.y * vr.y;
+    D2(x)[i] = vx;
+    D2(r)[i] = vr;
+    D2(z)[i] = vz;
+  }
+  __device__ void one(int i) const
+  {
+    double vz = z[i];
+    x[i] += vz;
+    double vr = r[i] - q[i];
+    r[i] = vr;
+    z[i] = c1 * vz + c2 * dinv[i] * vr;
+  }
+};
+struct ChebFirstF
+{ // first step from x == 0:  x = z ; r -= q ; z = c1 z + c2 dinv r
+  double* x;
+  double* r;
+  double* z;
+  const double* q;
+  const double* dinv;
+  double c1, c2;
+  __device__ void pair(int i) const
+  {
+    double2 vr = D2(r)[i], vz = D2(z)[i];
+    double2 vq = CD2(q)[i], vd = CD2(dinv)[i];
+    D2(x)[i] = vz;
+    vr.x -= vq.x;
+    vr.y -= vq.y;
+    vz.x = c1 * vz.x + c2 * vd.x * vr.x;
+    vz.y = c1 * vz.y + c2 * vd.y * vr.y;
+    D2(r)[i] = vr;
+    D2(z)[i] = vz;
+  }
+  __device__ void one(int i) const
+  {
+    double vz = z[i];
+    x[i] = vz;
+    double vr = r[i] - q[i];
+    r[i] = vr;
+    z[i] = c1 * vz + c2 * dinv[i] * vr;
+  }
+};
+struct AddF
+{ // x += z
+  double* x;
+  const double* z;
+  __device__ void pair(int i) const
+  {
+    double2 vx = D2(x)[i], vz = CD2(z)[i];
+    D2(x)[i] = make_double2(vx.x + vz.x, vx.y + vz.y);
+  }
+  __device__ void one(int i) const { x[i] += z[i]; }
+};
+struct MaskBcF
+{ // b *= (1 - bc)   (src/pmg.hpp:100-103)
+  double* b;
+  const int8_t* bc;
+  __device__ void pair(int i) const
+  {
+    if (bc[2 * i])
+      b[2 * i] = 0.0;
+    if (bc[2 * i + 1])
+      b[2 * i + 1] = 0.0;
+  }
+  __device__ void one(int i) const
+  {
+    if (bc[i])
+      b[i] = 0.0;
+  }
+};
+struct CgUpdateF
+{ // x += alpha p ; r -= alpha y ; y = dinv r   (src/cg.hpp:186-192)
+  double* x;
+  double* r;
+  double* y;
+  const double* p;
+  const double* dinv;
+  double alpha;
+  __device__ void pair(int i) const
+  {
+    double2 vx = D2(x)[i], vr = D2(r)[i], vy = D2(y)[i];
+    double2 vp = CD2(p)[i], vd = CD2(dinv)[i];
+    vx.x += alpha * vp.x;
+    vx.y += alpha * vp.y;
+    vr.x -= alpha * vy.x;
+    vr.y -= alpha * vy.y;
+    D2(x)[i] = vx;
+    D2(r)[i] = vr;
+    D2(y)[i] = make_double2(vd.x * vr.x, vd.y * vr.y);
+  }
+  __device__ void one(int i) const
+  {
+    x[i] += alpha * p[i];
+    double vr = r[i] - alpha * y[i];
+    r[i] = vr;
+    y[i] = dinv[i] * vr;
+  }
+};
+
+// ---- reductions: block partials, then one block folds them (deterministic) ----
+__device__ inline double wave_sum(double v)
+{
+  for (int off = 32; off > 0; off >>= 1)
+    v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ inline double wave_max(double v)
+{
+  for (int off = 32; off > 0; off >>= 1)
+    v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+template <bool MAX>
+__device__ inline double block_reduce(double v)
+{
+  __shared__ double sm[RED_THREADS / 64];
+  v = MAX ? wave_max(v) : wave_sum(v);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0)
+    sm[w] = v;
+  __syncthreads();
+  if (w == 0)
+  {
+    v = lane < RED_THREADS / 64 ? sm[lane] : (MAX ? 0.0 : 0.0);
+    v = MAX ? wave_max(v) : wave_sum(v);
+  }
+  return v;
+}
+
+__global__ void dot_partial_kernel(int n, const double* __restrict__ a,
+                                   const double* __restrict__ b, double* __restrict__ partials,
+                                   int vec)
+{
+  double acc = 0.0;
+  if (vec)
+  {
+    int n2 = n / 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += gridDim.x * blockDim.x)
+    {
+      double2 va = CD2(a)[i], vb = CD2(b)[i];
+      acc += va.x * vb.x + va.y * vb.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+      acc += a[n - 1] * b[n - 1];
+  }
+  else
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+      acc += a[i] * b[i];
+  acc = block_reduce<false>(acc);
+  if (threadIdx.x == 0)
+    partials[blockIdx.x] = acc;
+}
+
+__global__ void absmax_partial_kernel(int n, const double* __restrict__ a,
+                                      double* __restrict__ partials)
+{
+  double acc = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    acc = fmax(acc, fabs(a[i]));
+  acc = block_reduce<true>(acc);
+  if (threadIdx.x == 0)
+    partials[blockIdx.x] = acc;
+}
+
+template <bool MAX>
+__global__ void fold_kernel(int nb, const double* __restrict__ partials, double* __restrict__ out)
+{
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x)
+    acc = MAX ? fmax(acc, partials[i]) : acc + partials[i];
+  acc = block_reduce<MAX>(acc);
+  if (threadIdx.x == 0)
+    out[0] = acc;
+}
+} // namespace
+
+namespace pmg
+{
+void launch_axpy(int n, double* r, double alpha, const double* x, const double* y, hipStream_t s)
+{
+  ew_launch(n, aligned16(r) && aligned16(x) && aligned16(y), AxpyF{r, alpha, x, y}, s);
+}
+void launch_pointwise(int n, double* w, const double* x, const double* y, hipStream_t s)
+{
+  ew_launch(n, aligned16(w) && aligned16(x) && aligned16(y), MulF{w, x, y}, s);
+}
+void launch_cheb_init(int n, double* r, double* z, const double* b, const double* q,
+                      const double* dinv, double c0, hipStream_t s)
+{
+  bool v = aligned16(r) && aligned16(z) && aligned16(b) && aligned16(dinv) && (!q || aligned16(q));
+  ew_launch(n, v, ChebInitF{r, z, b, q, dinv, c0}, s);
+}
+void launch_cheb_step(int n, double* x, double* r, double* z, const double* q, const double* dinv,
+                      double c1, double c2, hipStream_t s)
+{
+  bool v = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(q) && aligned16(dinv);
+  ew_launch(n, v, ChebStepF{x, r, z, q, dinv, c1, c2}, s);
+}
+void launch_cheb_first(int n, double* x, double* r, double* z, const double* q, const double* dinv,
+                       double c1, double c2, hipStream_t s)
+{
+  bool v = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(q) && aligned16(dinv);
+  ew_launch(n, v, ChebFirstF{x, r, z, q, dinv, c1, c2}, s);
+}
+void launch_add(int n, double* x, const double* z, hipStream_t s)
+{
+  ew_launch(n, aligned16(x) && aligned16(z), AddF{x, z}, s);
+}
+void launch_mask_bc(int n, double* b, const int8_t* bc, hipStream_t s)
+{
+  ew_launch(n, true, MaskBcF{b, bc}, s);
+}
+void launch_cg_update(int n, double* x, double* r, double* y, const double* p, const double* dinv,
+                      double alpha, hipStream_t s)
+{
+  bool v = aligned16(x) && aligned16(r) && aligned16(y) && aligned16(p) && aligned16(dinv);
+  ew_launch(n, v, CgUpdateF{x, r, y, p, dinv, alpha}, s);
+}
+
+// local (this rank) dot of the owned entries -> d_out[0], stream-ordered
+int dot_async(pmg_layout l, const double* a, const double* b, double* d_out, hipStream_t s)
+{
+  int n = l->size_local;
+  int nb = ew_blocks((n + 1) / 2);
+  if (nb > RED_BLOCKS)
+    nb = RED_BLOCKS;
+  int vec = aligned16(a) && aligned16(b);
+  dot_partial_kernel<<<nb, RED_THREADS, 0, s>>>(n, a, b, l->d_partials, vec);
+  fold_kernel<false><<<1, RED_THREADS, 0, s>>>(nb, l->d_partials, d_out);
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+// inner_product of src/vector.hpp:334-352: local dot, host value, all-reduce
+int dot_host(pmg_layout l, const double* a, const double* b, double* result, hipStream_t s)
+{
+  PMG_TRY(dot_async(l, a, b, l->d_partials + RED_BLOCKS, s));
+  PMG_HIP(hipMemcpyAsync(l->h_result, l->d_partials + RED_BLOCKS, sizeof(double),
+                         hipMemcpyDeviceToHost, s));
+  PMG_HIP(hipStreamSynchronize(s));
+  double v = l->h_result[0];
+  if (l->allreduce)
+  {
+    if (l->allreduce(l->user, &v, 1) != 0)
+      return fail(PMG_ERR_INVALID, "allreduce callback failed");
+  }
+  *result = v;
+  return PMG_OK;
+}
+} // namespace pmg
+
+// ------------------------------------------------------------------ C ABI --
+extern "C" int pmg_layout_create(pmg_layout* out, int32_t size_local, int32_t num_ghosts,
+                                 int32_t n_send, const int32_t* send_indices, double* send_buffer,
+                                 int32_t n_recv, const int32_t* recv_indices, double* recv_buffer,
+                                 pmg_exchange_fn exchange, pmg_allreduce_fn allreduce_sum,
+                                 void* user)
+{
+  PMG_REQUIRE(out, "pmg_layout_create: out is NULL");
+  PMG_REQUIRE(size_local >= 0 && num_ghosts >= 0 && n_send >= 0 && n_recv >= 0,
+              "pmg_layout_create: negative size");
+  PMG_REQUIRE(n_recv <= num_ghosts, "pmg_layout_create: n_recv (%d) > num_ghosts (%d)", n_recv,
+              num_ghosts);
+  PMG_REQUIRE(n_send == 0 || (send_indices && send_buffer),
+              "pmg_layout_create: send arrays missing");
+  PMG_REQUIRE(n_recv == 0 || (recv_indices && recv_buffer),
+              "pmg_layout_create: recv arrays missing");
+  PMG_REQUIRE((n_send == 0 && n_recv == 0) || exchange,
+              "pmg_layout_create: neighbours given but no exchange callback");
+  auto* l = new pmg_layout_s;
+  l->size_local = size_local;
+  l->num_ghosts = num_ghosts;
+  l->n_send = n_send;
+  l->n_recv = n_recv;
+  l->send_idx = send_indices;
+  l->recv_idx = recv_indices;
+  l->send_buf = send_buffer;
+  l->recv_buf = recv_buffer;
+  l->exchange = exchange;
+  l->allreduce = allreduce_sum;
+  l->user = user;
+  hipError_t e = hipMalloc(&l->d_partials, sizeof(double) * (RED_BLOCKS + 8));
+  if (e == hipSuccess)
+    e = hipHostMalloc(&l->h_result, sizeof(double) * 4, hipHostMallocDefault);
+  if (e != hipSuccess)
+  {
+    delete l;
+    return fail(PMG_ERR_HIP, "pmg_layout_create: %s", hipGetErrorString(e));
+  }
+  *out = l;
+  return PMG_OK;
+}
+
+extern "C" int pmg_layout_destroy(pmg_layout l)
+{
+  if (!l)
+    return PMG_OK;
+  (void)hipFree(l->d_partials);
+  (void)hipHostFree(l->h_result);
+  delete l;
+  return PMG_OK;
+}
+
+extern "C" int32_t pmg_layout_size_local(pmg_layout l) { return l ? l->size_local : -1; }
+extern "C" int32_t pmg_layout_num_ghosts(pmg_layout l) { return l ? l->num_ghosts : -1; }
+
+// src/vector.hpp:186-207
+extern "C" int pmg_scatter_fwd_begin(pmg_layout l, const double* x, pmg_stream stream)
+{
+  PMG_REQUIRE(l && x, "pmg_scatter_fwd_begin: NULL argument");
+  if (l->n_send == 0 && l->n_recv == 0)
+    return PMG_OK;
+  if (l->n_send > 0)
+    pack_kernel<<<ew_blocks(l->n_send), EW_THREADS, 0, S(stream)>>>(l->n_send, l->send_idx, x,
+                                                                    l->send_buf);
+  PMG_HIP(hipGetLastError());
+  if (l->exchange(l->user, 0, stream) != 0)
+    return fail(PMG_ERR_INVALID, "exchange callback (begin) failed");
+  return PMG_OK;
+}
+
+// src/vector.hpp:209-238
+extern "C" int pmg_scatter_fwd_end(pmg_layout l, double* x, pmg_stream stream)
+{
+  PMG_REQUIRE(l && x, "pmg_scatter_fwd_end: NULL argument");
+  if (l->n_send == 0 && l->n_recv == 0)
+    return PMG_OK;
+  if (l->exchange(l->user, 1, stream) != 0)
+    return fail(PMG_ERR_INVALID, "exchange callback (end) failed");
+  if (l->n_recv > 0)
+    unpack_kernel<<<ew_blocks(l->n_recv), EW_THREADS, 0, S(stream)>>>(
+        l->n_recv, l->recv_idx, l->recv_buf, x + l->size_local);
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+// src/vector.hpp:249-267: ghosts are packed into the *recv* buffer and travel
+// back to their owners, who receive them in the *send* buffer.
+extern "C" int pmg_scatter_rev_begin(pmg_layout l, const double* x, pmg_stream stream)
+{
+  PMG_REQUIRE(l && x, "pmg_scatter_rev_begin: NULL argument");
+  if (l->n_send == 0 && l->n_recv == 0)
+    return PMG_OK;
+  if (l->n_recv > 0)
+    pack_kernel<<<ew_blocks(l->n_recv), EW_THREADS, 0, S(stream)>>>(
+        l->n_recv, l->recv_idx, x + l->size_local, l->recv_buf);
+  PMG_HIP(hipGetLastError());
+  if (l->exchange(l->user, 2, stream) != 0)
+    return fail(PMG_ERR_INVALID, "exchange callback (rev begin) failed");
+  return PMG_OK;
+}
+
+// src/vector.hpp:270-286
+extern "C" int pmg_scatter_rev_end(pmg_layout l, double* x, pmg_stream stream)
+{
+  PMG_REQUIRE(l && x, "pmg_scatter_rev_end: NULL argument");
+  if (l->n_send == 0 && l->n_recv == 0)
+    return PMG_OK;
+  if (l->exchange(l->user, 3, stream) != 0)
+    return fail(PMG_ERR_INVALID, "exchange callback (rev end) failed");
+  if (l->n_send > 0)
+    unpack_add_kernel<<<ew_blocks(l->n_send), EW_THREADS, 0, S(stream)>>>(l->n_send, l->send_idx,
+                                                                          l->send_buf, x);
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+extern "C" int pmg_vec_set(pmg_layout l, double* x, double value, pmg_stream stream)
+{
+  PMG_REQUIRE(l && x, "pmg_vec_set: NULL argument");
+  ew_launch(l->total(), aligned16(x), SetF{x, value}, S(stream));
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+extern "C" int pmg_vec_scale(pmg_layout l, double* x, double alpha, pmg_stream stream)
+{
+  PMG_REQUIRE(l && x, "pmg_vec_scale: NULL argument");
+  ew_launch(l->total(), aligned16(x), ScaleF{x, alpha}, S(stream));
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+extern "C" int pmg_vec_copy(pmg_layout l, double* dst, const double* src, pmg_stream stream)
+{
+  PMG_REQUIRE(l && dst && src, "pmg_vec_copy: NULL argument");
+  ew_launch(l->size_local, aligned16(dst) && aligned16(src), CopyF{dst, src}, S(stream));
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+extern "C" int pmg_vec_axpy(pmg_layout l, double* r, double alpha, const double* x,
+                            const double* y, pmg_stream stream)
+{
+  PMG_REQUIRE(l && r && x && y, "pmg_vec_axpy: NULL argument");
+  launch_axpy(l->size_local, r, alpha, x, y, S(stream));
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+extern "C" int pmg_vec_pointwise_mult(pmg_layout l, double* w, const double* x, const double* y,
+                                      pmg_stream stream)
+{
+  PMG_REQUIRE(l && w && x && y, "pmg_vec_pointwise_mult: NULL argument");
+  launch_pointwise(l->size_local, w, x, y, S(stream));
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+extern "C" int pmg_vec_inner_product(pmg_layout l, const double* a, const double* b,
+                                     double* result, pmg_stream stream)
+{
+  PMG_REQUIRE(l && a && b && result, "pmg_vec_inner_product: NULL argument");
+  return dot_host(l, a, b, result, S(stream));
+}
+
+extern "C" int pmg_vec_squared_norm(pmg_layout l, const double* a, double* result,
+                                    pmg_stream stream)
+{
+  return pmg_vec_inner_product(l, a, a, result, stream);
+}
+
+extern "C" int pmg_vec_norm(pmg_layout l, const double* a, int norm_type, double* result,
+                            pmg_stream stream)
+{
+  PMG_REQUIRE(l && a && result, "pmg_vec_norm: NULL argument");
+  if (norm_type == 0)
+  {
+    double v;
+    PMG_TRY(dot_host(l, a, a, &v, S(stream)));
+    *result = sqrt(v);
+    return PMG_OK;
+  }
+  PMG_REQUIRE(norm_type == 1, "Norm type not supported"); // src/vector.hpp:388
+  PMG_REQUIRE(!l->allreduce, "pmg_vec_norm: linf needs a max-reduction, not available through "
+                             "the sum-only allreduce callback");
+  int nb = ew_blocks(l->size_local);
+  if (nb > RED_BLOCKS)
+    nb = RED_BLOCKS;
+  absmax_partial_kernel<<<nb, RED_THREADS, 0, S(stream)>>>(l->size_local, a, l->d_partials);
+  fold_kernel<true><<<1, RED_THREADS, 0, S(stream)>>>(nb, l->d_partials, l->d_partials + RED_BLOCKS);
+  PMG_HIP(hipGetLastError());
+  PMG_HIP(hipMemcpyAsync(l->h_result, l->d_partials + RED_BLOCKS, sizeof(double),
+                         hipMemcpyDeviceToHost, S(stream)));
+  PMG_HIP(hipStreamSynchronize(S(stream)));
+  *result = l->h_result[0];
+  return PMG_OK;
+}

@@ -1,0 +1,120 @@
+"""Host mirror of ``acc::MatFreeLaplacian`` (``src/laplacian.hpp:284-526``)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import call, current_stream, ptr, vp
+from .vector import Layout, Vector
+
+
+def _dev_i32(a, device):
+    import torch
+
+    if hasattr(a, "data_ptr"):
+        return a
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+
+
+def _dev_f64(a, device):
+    import torch
+
+    if hasattr(a, "data_ptr"):
+        return a
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+
+
+def _dev_i8(a, device):
+    import torch
+
+    if hasattr(a, "data_ptr"):
+        return a
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int8)).to(device)
+
+
+class MatFreeLaplacian:
+    """y = A x for the GLL-collocated stiffness operator, matrix-free.
+
+    Argument order follows the reference constructor (``:289-297``); arrays may be
+    numpy (uploaded here) or device torch tensors (used in place -- they must
+    outlive the operator, exactly like the reference's non-owning spans).  The
+    coordinate-element tabulation ``dphi_geometry`` and ``G_weights`` of the
+    reference are derived from ``degree`` inside the library.
+    """
+
+    value_type = np.float64
+
+    def __init__(self, degree, coefficients, dofmap, xgeom, geometry_dofmap, lcells, bcells, bc_marker,
+                 layout: Layout, batch_size: int = 0):
+        if batch_size != 0:
+            # src/laplacian.hpp:391-396 recomputes G per batch to save memory; with
+            # 288 GB of HBM the tensor is always resident.
+            raise ValueError("geometry batching is not supported: G is kept resident in HBM")
+        dev = layout.device
+        self.layout = layout
+        self.degree = int(degree)
+        N = (self.degree + 1) ** 3
+        self.dofmap = _dev_i32(dofmap, dev)
+        self.ncells = int(self.dofmap.numel() // N) if self.degree >= 1 else 0
+        self.kappa = _dev_f64(np.broadcast_to(np.asarray(coefficients, dtype=np.float64), (self.ncells,)).copy()
+                              if not hasattr(coefficients, "data_ptr") else coefficients, dev)
+        self.xgeom = _dev_f64(xgeom, dev)
+        self.geom_dofmap = _dev_i32(geometry_dofmap, dev)
+        self.bc_marker = _dev_i8(bc_marker, dev)
+        if self.bc_marker.numel() != layout.total:
+            raise ValueError("bc_marker must have size_local + num_ghosts entries")
+        lc = np.ascontiguousarray(lcells, dtype=np.int32)
+        bc_ = np.ascontiguousarray(bcells, dtype=np.int32)
+        h = vp()
+        call("pmg_laplacian_create", C.byref(h), layout.handle, self.degree, self.ncells, ptr(self.kappa),
+             ptr(self.dofmap), ptr(self.xgeom), int(self.xgeom.numel() // 3), ptr(self.geom_dofmap),
+             lc.ctypes.data_as(_lib.c_ip), lc.size, bc_.ctypes.data_as(_lib.c_ip), bc_.size, ptr(self.bc_marker),
+             current_stream())
+        self._handle = h
+
+    @property
+    def handle(self):
+        return self._handle
+
+    def __call__(self, x: Vector, y: Vector):  # operator()(in, out), :462-482
+        call("pmg_laplacian_apply", self._handle, ptr(x.data), ptr(y.data), current_stream())
+
+    def get_diag_inverse(self, diag_inv: Vector):  # :484-488
+        call("pmg_laplacian_get_diag_inverse", self._handle, ptr(diag_inv.data), current_stream())
+
+    def set_diag_inverse(self, diag_inv: Vector):  # :490-495
+        call("pmg_laplacian_set_diag_inverse", self._handle, ptr(diag_inv.data), current_stream())
+
+    def compute_diag_inverse(self):
+        """Matrix-free replacement of the CSR detour of ``examples/pmg/main.cpp:274-279``."""
+        call("pmg_laplacian_compute_diag_inverse", self._handle, current_stream())
+
+    def geometry(self):
+        """G in the reference layout [ncells, nq, 6] (device tensor)."""
+        import torch
+
+        N = (self.degree + 1) ** 3
+        out = torch.empty((self.ncells, N, 6), dtype=torch.float64, device=self.layout.device)
+        call("pmg_laplacian_get_geometry", self._handle, ptr(out), current_stream())
+        return out
+
+    def assemble_rhs(self, f: Vector, b: Vector):
+        call("pmg_laplacian_assemble_rhs", self._handle, ptr(f.data), ptr(b.data), current_stream())
+
+    def time_kernel(self, x: Vector, y: Vector, reps: int) -> float:
+        """Mean milliseconds of one stiffness-kernel launch over all local cells
+        (HIP events on the launch stream)."""
+        out = C.c_double()
+        call("pmg_laplacian_time_kernel", self._handle, ptr(x.data), ptr(y.data), int(reps), C.byref(out),
+             current_stream())
+        return out.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                _lib.lib().pmg_laplacian_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass

@@ -1,0 +1,278 @@
+"""Distributed vector: host mirror of ``acc::Vector`` and the BLAS-1 free
+functions of ``src/vector.hpp``.
+
+``Layout`` plays the role of dolfinx's ``IndexMap`` + ``Scatterer`` pair the
+reference constructs a vector from (``src/vector.hpp:83-96``): sizes, the packed
+send/receive index lists, staging buffers, and the neighbour exchange itself.
+The exchange is ``torch.distributed.all_to_all_single`` with per-neighbour split
+sizes -- on the ``nccl`` backend that is one grouped ncclSend/ncclRecv over xGMI
+(RCCL), issued on RCCL's own stream so that it overlaps the interior-cell kernel
+the library enqueues between ``begin`` and ``end`` (``src/laplacian.hpp:378-425``).
+The library calls back into :meth:`Layout._exchange` from
+``pmg_scatter_fwd_begin/_end``; pack and unpack are HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import call, current_stream, ptr, vp
+
+_REGISTRY = {}  # id -> Layout, keeps callbacks' targets alive
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist
+
+
+class Layout:
+    """Sizes + halo plan of one function space on this rank.
+
+    Parameters mirror the flattened IndexMap/Scatterer of the C ABI:
+    ``neighbors`` (ranks, ascending), per-neighbour ``send_counts`` /
+    ``recv_counts``, ``send_indices`` (owned positions, grouped by neighbour),
+    ``recv_indices`` (ghost positions relative to ``size_local``).
+    """
+
+    def __init__(self, size_local, num_ghosts=0, neighbors=(), send_counts=(), recv_counts=(), send_indices=None,
+                 recv_indices=None, group=None, device="cuda"):
+        import torch
+
+        self.size_local = int(size_local)
+        self.num_ghosts = int(num_ghosts)
+        self.neighbors = [int(r) for r in neighbors]
+        self.send_counts = [int(c) for c in send_counts]
+        self.recv_counts = [int(c) for c in recv_counts]
+        self.group = group
+        self.device = torch.device(device)
+        n_send, n_recv = sum(self.send_counts), sum(self.recv_counts)
+        self.n_send, self.n_recv = n_send, n_recv
+        si = np.zeros(0, np.int32) if send_indices is None else np.ascontiguousarray(send_indices, dtype=np.int32)
+        ri = np.zeros(0, np.int32) if recv_indices is None else np.ascontiguousarray(recv_indices, dtype=np.int32)
+        if si.size != n_send or ri.size != n_recv:
+            raise ValueError("index list lengths do not match the per-neighbour counts")
+        if n_send and (si.min() < 0 or si.max() >= self.size_local):
+            raise ValueError("send_indices out of the owned range")
+        if n_recv and (ri.min() < 0 or ri.max() >= self.num_ghosts):
+            raise ValueError("recv_indices out of the ghost range")
+        self.send_indices_host, self.recv_indices_host = si, ri
+        self.distributed = bool(self.neighbors)
+        self._work = None
+        self._handle = None
+        if self.device.type != "cuda":
+            return  # host-only layout (set-up exchanges, CPU tests); no library object
+        self.send_indices = torch.from_numpy(si).to(self.device)
+        self.recv_indices = torch.from_numpy(ri).to(self.device)
+        self.send_buffer = torch.zeros(max(n_send, 1), dtype=torch.float64, device=self.device)
+        self.recv_buffer = torch.zeros(max(n_recv, 1), dtype=torch.float64, device=self.device)
+        dist = _dist()
+        self._world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self._splits()
+        # callbacks must outlive the handle
+        self._cb_exchange = _lib.EXCHANGE_FN(self._exchange) if self.distributed else _lib.EXCHANGE_FN()
+        self._cb_allreduce = _lib.ALLREDUCE_FN(self._allreduce) if self._world > 1 else _lib.ALLREDUCE_FN()
+        h = vp()
+        call("pmg_layout_create", C.byref(h), self.size_local, self.num_ghosts, n_send, ptr(self.send_indices),
+             ptr(self.send_buffer), n_recv, ptr(self.recv_indices), ptr(self.recv_buffer), self._cb_exchange,
+             self._cb_allreduce, vp(0))
+        self._handle = h
+        _REGISTRY[id(self)] = self
+
+    # ---- per-rank split sizes for all_to_all_single ----
+    def _splits(self):
+        dist = _dist()
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        self._world = world
+        self._send_splits = [0] * world
+        self._recv_splits = [0] * world
+        for r, s, c in zip(self.neighbors, self.send_counts, self.recv_counts):
+            self._send_splits[r] = s
+            self._recv_splits[r] = c
+
+    # ---- callbacks (invoked from inside pmg_scatter_*; torch's current stream is
+    #      the stream the library was given) ----
+    def _exchange(self, user, phase, stream):
+        try:
+            dist = _dist()
+            if phase == 0:  # forward begin: owners' packed values -> ghosts
+                self._work = dist.all_to_all_single(
+                    self.recv_buffer[: self.n_recv], self.send_buffer[: self.n_send], self._recv_splits,
+                    self._send_splits, group=self.group, async_op=True)
+            elif phase == 2:  # reverse begin: ghost values -> owners
+                self._work = dist.all_to_all_single(
+                    self.send_buffer[: self.n_send], self.recv_buffer[: self.n_recv], self._send_splits,
+                    self._recv_splits, group=self.group, async_op=True)
+            else:  # 1, 3: make the compute stream wait for the arrival
+                if self._work is not None:
+                    self._work.wait()
+                    self._work = None
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            import sys
+            import traceback
+
+            traceback.print_exc(file=sys.stderr)
+            return 1
+
+    def _allreduce(self, user, values, n):
+        try:
+            import torch
+
+            dist = _dist()
+            host = np.ctypeslib.as_array(values, shape=(n,))
+            t = torch.from_numpy(host.copy())
+            if dist.get_backend(self.group) == "nccl":
+                t = t.to(self.device)
+            dist.all_reduce(t, group=self.group)
+            host[:] = t.cpu().numpy()
+            return 0
+        except Exception:
+            import sys
+            import traceback
+
+            traceback.print_exc(file=sys.stderr)
+            return 1
+
+    # ---- host-side forward scatter of a numpy array (set-up and CPU tests) ----
+    def scatter_fwd_host(self, x: np.ndarray) -> np.ndarray:
+        """Owner -> ghost update of a host array of size_local + num_ghosts entries
+        with the same plan, over whatever backend the process group uses."""
+        import torch
+
+        dist = _dist()
+        if not (dist.is_available() and dist.is_initialized()) or not self.distributed:
+            return x
+        self._splits()
+        send = torch.from_numpy(np.ascontiguousarray(x[self.send_indices_host]))
+        recv = torch.empty(self.n_recv, dtype=send.dtype)
+        if dist.get_backend(self.group) == "nccl":
+            send, recv = send.to(self.device), recv.to(self.device)
+        dist.all_to_all_single(recv, send, self._recv_splits, self._send_splits, group=self.group)
+        x[self.size_local + self.recv_indices_host] = recv.cpu().numpy()
+        return x
+
+    @property
+    def handle(self):
+        if self._handle is None:
+            raise RuntimeError("host-only Layout has no device handle")
+        return self._handle
+
+    @property
+    def total(self):
+        return self.size_local + self.num_ghosts
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.lib().pmg_layout_destroy(self._handle)
+                self._handle = None
+            _REGISTRY.pop(id(self), None)
+        except Exception:
+            pass
+
+
+class Vector:
+    """``acc::Vector<T, Device::HIP>`` (``src/vector.hpp:74-325``): owned entries
+    followed by ghosts, device resident (a torch tensor is the storage)."""
+
+    def __init__(self, layout: Layout, bs: int = 1):
+        import torch
+
+        if bs != 1:
+            raise ValueError("block size 1 only (the reference hot path uses bs = 1)")
+        self.layout = layout
+        self._x = torch.zeros(layout.total, dtype=torch.float64, device=layout.device)
+
+    # -- reference API --
+    def set(self, v: float):  # :109-115
+        call("pmg_vec_set", self.layout.handle, ptr(self._x), float(v), current_stream())
+
+    def copy_from_host(self, other):  # :117-122 (owned part only)
+        import torch
+
+        a = np.asarray(other.array() if hasattr(other, "array") and callable(other.array) else other, dtype=np.float64)
+        n = self.layout.size_local
+        self._x[:n].copy_(torch.from_numpy(np.ascontiguousarray(a[:n])), non_blocking=False)
+
+    def array(self):  # :141-150
+        return self._x
+
+    def mutable_array(self):  # :153-162
+        return self._x
+
+    def map(self):
+        return self.layout
+
+    def bs(self):
+        return 1
+
+    def scatter_fwd_begin(self):  # :186-207
+        call("pmg_scatter_fwd_begin", self.layout.handle, ptr(self._x), current_stream())
+
+    def scatter_fwd_end(self):  # :209-238
+        call("pmg_scatter_fwd_end", self.layout.handle, ptr(self._x), current_stream())
+
+    def scatter_fwd(self):  # :242-246
+        self.scatter_fwd_begin()
+        self.scatter_fwd_end()
+
+    def scatter_rev_begin(self):  # :249-267
+        call("pmg_scatter_rev_begin", self.layout.handle, ptr(self._x), current_stream())
+
+    def scatter_rev_end(self):  # :270-286
+        call("pmg_scatter_rev_end", self.layout.handle, ptr(self._x), current_stream())
+
+    def scatter_rev(self):
+        self.scatter_rev_begin()
+        self.scatter_rev_end()
+
+    def data_copy(self):  # :297-302
+        return self._x.cpu().numpy()
+
+    @property
+    def data(self):
+        return self._x
+
+
+def _h(v: Vector):
+    return v.layout.handle
+
+
+def inner_product(a: Vector, b: Vector) -> float:  # :334-352
+    if a.layout.size_local != b.layout.size_local:
+        raise RuntimeError("Incompatible vector sizes")  # :343
+    out = C.c_double()
+    call("pmg_vec_inner_product", _h(a), ptr(a.data), ptr(b.data), C.byref(out), current_stream())
+    return out.value
+
+
+def squared_norm(a: Vector) -> float:  # :357-362
+    return inner_product(a, a)
+
+
+def norm(a: Vector, kind: str = "l2") -> float:  # :369-390
+    if kind not in ("l2", "linf"):
+        raise RuntimeError("Norm type not supported")
+    out = C.c_double()
+    call("pmg_vec_norm", _h(a), ptr(a.data), 0 if kind == "l2" else 1, C.byref(out), current_stream())
+    return out.value
+
+
+def axpy(r: Vector, alpha: float, x: Vector, y: Vector):  # :398-407, r = alpha x + y
+    call("pmg_vec_axpy", _h(r), ptr(r.data), float(alpha), ptr(x.data), ptr(y.data), current_stream())
+
+
+def scale(r: Vector, alpha: float):  # :413-418
+    call("pmg_vec_scale", _h(r), ptr(r.data), float(alpha), current_stream())
+
+
+def copy(a: Vector, b: Vector):  # :424-431, a = b
+    call("pmg_vec_copy", _h(a), ptr(a.data), ptr(b.data), current_stream())
+
+
+def pointwise_mult(w: Vector, x: Vector, y: Vector):  # :438-447
+    call("pmg_vec_pointwise_mult", _h(w), ptr(w.data), ptr(x.data), ptr(y.data), current_stream())

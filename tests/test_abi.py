@@ -1,0 +1,73 @@
+"""The C-ABI library on a machine without a GPU: it loads, exports every symbol
+include/pmg_amd.h declares, and its host-only entry points (tables, TQLI, error
+reporting) agree with the oracle / the reference fixture.  No compute calls."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+
+from oracle import pmg_oracle as po
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "pmg_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(pmg_[a-z0-9_]+)\s*\(", src))
+    return sorted(names - {"pmg_exchange_fn", "pmg_allreduce_fn"})
+
+
+def test_every_declared_symbol_is_exported_and_bound(built):
+    import pmg_dolfinx_amd as pm
+
+    L = C.CDLL(pm._lib.LIB_PATH)
+    declared = _declared()
+    assert len(declared) >= 50
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in pmg_amd.h but not exported"
+    assert sorted(pm._lib.exported_symbols()) == declared  # the Python binding covers the whole ABI
+    assert pm._lib.lib().pmg_version() >= 100
+
+
+def test_host_tables_match_oracle(built):
+    from pmg_dolfinx_amd import _tables as t
+
+    for n in range(2, 10):
+        x, w = t.gll_points_weights(n)
+        xo, wo = po.gll_points_weights(n)
+        assert np.abs(x - xo).max() < 1e-15 and np.abs(w - wo).max() < 1e-15
+        D, Do = t.lagrange_derivative_table(n), po.lagrange_deriv_matrix(xo)
+        assert np.abs(D - Do).max() < 1e-13 * np.abs(Do).max()
+    for pc, pf in ((1, 2), (2, 4), (1, 3), (3, 6), (4, 8)):
+        assert np.abs(t.interpolation_table(pc, pf) - po.interpolation_matrix_1d(pc, pf)).max() < 1e-14
+
+
+def test_tqli_golden_and_errors(built):
+    import pmg_dolfinx_amd as pm
+    from pmg_dolfinx_amd import _tables as t
+
+    cases = json.load(open(os.path.join(HERE, "golden", "tqli_golden.json")))["cases"]
+    for case in cases:
+        d = t.tqli(case["d"], case["e"])
+        assert np.allclose(d, case["tqli_d_out"], rtol=1e-13, atol=0)
+    L = pm._lib.lib()
+    x = np.zeros(1)
+    rc = L.pmg_gll_table(1, x.ctypes.data_as(pm._lib.c_dp), x.ctypes.data_as(pm._lib.c_dp))
+    assert rc == -1 and b"n" in L.pmg_last_error()
+
+
+def test_missing_library_fails_loudly(built, monkeypatch):
+    import pmg_dolfinx_amd as pm
+
+    monkeypatch.setattr(pm._lib, "_lib", None)
+    monkeypatch.setattr(pm._lib, "LIB_PATH", "/nonexistent/libpmg_amd.so")
+    try:
+        pm._lib.lib()
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("loading a missing library must raise")
