@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- DoFs/sec of one p-multigrid V-cycle (Poisson, hex, p = 4) on MI355X.
+
+A "step" is one V-cycle (src/pmg.hpp:56-155 semantics) of the BASELINE.json
+config-2 workload: 64^3 hexes per GPU, levels p = 4 -> 2 -> 1, 4th-kind
+Chebyshev(3)/Jacobi smoothing on every level, lambda_max from 20 Jacobi-CG
+iterations (examples/pmg/main.cpp:306-330), kappa = 2, homogeneous Dirichlet,
+RHS = GLL-collocated -kappa lap(sin 2 pi x sin 3 pi y sin 4 pi z).  All inputs are
+synthetic and resident in HBM before the timed region.  Multi-GPU: one process
+per GPU (torch.distributed / RCCL), brick partition with one ghost-cell layer,
+weak scaling (64^3 cells per GPU), forward halo overlapped with interior cells.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W]
+        (N > 1: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def algorithmic_bytes_per_cell(P: int) -> int:
+    """SURVEY.md 8(d), model storedG: 48N [G] + 4N [dofmap] + 8 [kappa] + 8U [x] + 8U [y] + U [bc]."""
+    N, U = (P + 1) ** 3, P**3
+    return 48 * N + 4 * N + 8 + 17 * U
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=64, help="cells per axis per GPU (weak) / in total (strong)")
+    ap.add_argument("--orders", type=str, default="1,2,4")
+    ap.add_argument("--cheb", type=int, default=3)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--kernel-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as ge
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import pmg_dolfinx_amd as pm
+
+    orders = tuple(int(p) for p in args.orders.split(","))
+    dims = pm.default_proc_dims(world)
+    n_global = tuple(args.n * d for d in dims) if args.scaling == "weak" else (args.n,) * 3
+
+    t0 = time.time()
+    H = pm.PoissonHierarchy(n_global, orders, kappa=2.0, cheb_its=args.cheb, proc_dims=dims, rank=rank, size=world)
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] setup {time.time() - t0:.1f}s dims={dims} n_global={n_global} "
+        f"local dofs={[lv.size_local for lv in H.levels]} ghosts={[lv.num_ghosts for lv in H.levels]} "
+        f"lmax={[round(e[1], 6) for e in H.eig_ranges]}")
+    P = orders[-1]
+    fine_dofs_global = H.part.global_ndofs(P)
+    b = H.rhs[-1]
+    x = H.new_vector()
+    x.set(0.0)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up, then EXACTLY K timed V-cycles (stationary iteration, examples/pmg/main.cpp:362-367) ----
+    for _ in range(args.warmup):
+        H.mg.apply(b, x)
+    sync_all()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        H.mg.apply(b, x)
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = fine_dofs_global * args.steps / elapsed
+    counts = H.mg.apply_counts()
+    rn = H.mg.apply(b, x, verbose=True)
+    log(f"[rank {rank}] residual norm after {args.warmup + args.steps + 1} cycles: {rn:.3e}; "
+        f"stiffness launches per cycle (coarse->fine): {counts}")
+
+    # ---- dominant kernel: the p = P stiffness kernel, HIP events on the launch stream ----
+    u, y = H.new_vector(), H.new_vector()
+    u.data.copy_(torch.randn(H.levels[-1].ndofs, dtype=torch.float64, device="cuda",
+                             generator=torch.Generator(device="cuda").manual_seed(0)))
+    op = H.operators[-1]
+    op.time_kernel(u, y, 3)
+    kernel_ms = op.time_kernel(u, y, args.kernel_reps)
+    nlaunch = op.launches_per_apply()  # one launch per patch colour (and cell list)
+    ncells_launch = H.part.ncells / nlaunch  # mean cells per launch (owned + ghost layer, all colours)
+    alg_bytes = algorithmic_bytes_per_cell(P) * ncells_launch
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic_r01.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(f"stiffness_p{P}_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": f"stiffness_kernel<{P}>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms": round(kernel_ms, 5), "cells_per_launch": ncells_launch,
+                "launches_per_apply": nlaunch, "apply_ms": round(kernel_ms * nlaunch, 5)}
+
+    out = {
+        "metric": "DoFs/sec per p-MG V-cycle (Poisson, hex, p=4)",
+        "value": value,
+        "unit": "DoF/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"Poisson p={P} V-cycle p=" + "->".join(str(p) for p in reversed(orders))
+                        + f", Chebyshev({args.cheb})/Jacobi, {args.n}^3 hexes per GPU" if args.scaling == "weak"
+                        else f"Poisson p={P} V-cycle, {args.n}^3 hexes total",
+            "cells_global": list(n_global),
+            "fine_dofs_global": fine_dofs_global,
+            "levels": list(reversed(orders)),
+            "cheb_iterations": args.cheb,
+            "partition": "x".join(str(d) for d in dims) + " bricks, 1 ghost-cell layer",
+            "stiffness_launches_per_cycle": {f"p{p}": c for p, c in zip(orders, counts)},
+        },
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline: the C/OpenMP port of the same lean V-cycle on the host cores (rank 0, N = 1) ----
+    if world == 1 and not args.no_cpu:
+        from oracle import c_oracle as co
+
+        t0 = time.time()
+        part = H.part
+        cl = [co.CLevel(p, 2.0, part.level(p).dofmap, part.xgeom, part.geom_dofmap, part.level(p).bc_marker)
+              for p in orders]
+        ci = [co.CInterp(cl[i], cl[i + 1]) for i in range(len(orders) - 1)]
+        cm = co.CMultigrid(cl, ci, [e[1] for e in H.eig_ranges], args.cheb)
+        bh = b.data_copy()
+        xc = np.zeros_like(bh)
+        cm.apply(bh, xc)  # first cycle from x0 = 0: also the parity check below
+        ncpu = 2
+        tc = time.perf_counter()
+        for _ in range(ncpu):
+            cm.apply(bh, xc)
+        cpu_s = (time.perf_counter() - tc) / ncpu
+        log(f"cpu baseline: setup {time.time() - t0 - cpu_s * ncpu:.1f}s, {cpu_s:.2f}s per V-cycle on "
+            f"{co.num_threads()} threads")
+        # parity in the same run: 3 GPU V-cycles from x0 = 0 against the 3 CPU ones
+        xg = H.new_vector()
+        xg.set(0.0)
+        for _ in range(1 + ncpu):
+            H.mg.apply(b, xg)
+        torch.cuda.synchronize()
+        got = xg.data_copy()
+        err = float(np.abs(got - xc).max() / np.abs(xc).max())
+        out["cpu_baseline"] = {"value": fine_dofs_global / cpu_s, "unit": "DoF/s", "cores": co.num_threads(),
+                               "kind": "port",
+                               "sample": f"{ncpu} V-cycles of the same workload ({args.n}^3 hexes, "
+                                         f"{fine_dofs_global} fine dofs), C/OpenMP oracle, after 1 warm-up cycle"}
+        out["parity"] = {"gpu_vs_cpu_oracle_rel_err_after_3_cycles": err, "tolerance": 1e-10}
+        if not err < 1e-10:
+            log(f"PARITY FAILURE: {err}")
+            out["parity"]["failed"] = True
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,7 +77,8 @@ int pmg_tqli(double* d, double* e, int n);
  * is called with phase 0 after the pack kernel has been enqueued on `stream`
  * (start moving send_buffer -> the neighbours' recv_buffer, asynchronously with
  * respect to `stream`), and with phase 1 before the unpack kernel is enqueued
- * (make `stream` wait for the arrival).  It must return 0.  With no neighbours
+ * (make `stream` wait for the arrival).  Phases 2 / 3 are the same for the
+ * reverse scatter (recv_buffer -> the owners' send_buffer).  It must return 0.  With no neighbours
  * (n_send == n_recv == 0) it is never called and may be NULL.
  *
  * `allreduce_sum` sums `n` host doubles over all ranks in place (the
@@ -138,11 +139,13 @@ int pmg_vec_norm(pmg_layout l, const double* a, int norm_type, double* result, p
  * (basix tabulations of the trilinear coordinate element and the 3-D GLL
  * weights); they are fully determined by `degree`, so the library builds them
  * itself -- pass them to pmg_laplacian_create_with_tables to override.
- * The constructor precomputes the geometry tensor G for every cell
+ * The constructor precomputes the geometry tensor G for every listed cell
  * (geometry_computation, :22-113, with the determinant expanded correctly and G
- * indexed by cell id -- SURVEY.md quirks Q1, Q2) and its own masked copy of the
- * dofmap; degrees 1..PMG_MAX_DEGREE are supported (the reference stops at 5,
- * :335-346). */
+ * tied to the cell, not to its position in the launched list -- SURVEY.md quirks
+ * Q1, Q2) and groups the cells into coloured patches (its own copy of the
+ * dofmap in patch form); it reads dofmap, bc_marker, xgeom and geom_dofmap back
+ * to the host once for that.  Degrees 1..PMG_MAX_DEGREE are supported (the
+ * reference stops at 5, :335-346). */
 int pmg_laplacian_create(pmg_laplacian* out, pmg_layout layout, int degree, int32_t ncells,
                          const double* kappa, const int32_t* dofmap, const double* xgeom,
                          int32_t npoints, const int32_t* geom_dofmap, const int32_t* lcells,
@@ -176,9 +179,13 @@ int pmg_laplacian_get_geometry(pmg_laplacian op, double* G_out, pmg_stream strea
  * b[bc] = 0.  `f` holds the nodal values of the source term. */
 int pmg_laplacian_assemble_rhs(pmg_laplacian op, const double* f, double* b, pmg_stream stream);
 int pmg_laplacian_degree(pmg_laplacian op);
-/* Dominant-kernel timing hook for bench.py: enqueue `reps` launches of the
- * stiffness kernel over every local cell (no halo, no zero-fill) bracketed by
- * HIP events on `stream`; returns the mean milliseconds per launch. */
+/* One operator application issues one stiffness-kernel launch per patch colour
+ * and cell list (8 on a structured single-rank box). */
+int pmg_laplacian_launches_per_apply(pmg_laplacian op);
+/* Dominant-kernel timing hook for bench.py: enqueue `reps` times every
+ * stiffness-kernel launch of one operator application (no halo, no zero-fill)
+ * bracketed by HIP events on `stream`; returns the mean milliseconds per launch
+ * (= time per application / pmg_laplacian_launches_per_apply). */
 int pmg_laplacian_time_kernel(pmg_laplacian op, const double* in, double* out, int reps,
                               double* ms_per_launch, pmg_stream stream);
 

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpmg_amd.so")
+LIB_PATH = os.environ.get("PMG_AMD_LIB") or os.path.join(_HERE, "lib", "libpmg_amd.so")
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)
@@ -69,6 +69,7 @@ _SIGS = {
     "pmg_laplacian_get_geometry": (C.c_int, [vp, vp, vp]),
     "pmg_laplacian_assemble_rhs": (C.c_int, [vp, vp, vp, vp]),
     "pmg_laplacian_degree": (C.c_int, [vp]),
+    "pmg_laplacian_launches_per_apply": (C.c_int, [vp]),
     "pmg_laplacian_time_kernel": (C.c_int, [vp, vp, vp, C.c_int, c_dp, vp]),
     "pmg_chebyshev_create": (C.c_int, [C.POINTER(vp), vp, C.c_double, C.c_double]),
     "pmg_chebyshev_destroy": (C.c_int, [vp]),
@@ -101,7 +102,7 @@ _SIGS = {
 
 # functions whose int return value is a count, not a status
 _COUNT_FUNCS = {"pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
-                "pmg_laplacian_degree"}
+                "pmg_laplacian_degree", "pmg_laplacian_launches_per_apply"}
 
 _lib = None
 

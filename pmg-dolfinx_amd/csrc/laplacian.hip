@@ -3,26 +3,34 @@
 // Replaces src/laplacian.hpp (geometry_computation :22-113, stiffness_operator
 // :143-278, MatFreeLaplacian :284-526) of the reference.
 //
-// HBM layout (all owned by the handle):
-//   G       [ncells][3][N] double2 : (G00,G01) (G02,G11) (G12,G22) per quadrature
-//           point, so that one wave reads 1 KiB contiguous per load instruction
-//           (the reference stores [cell][q][6] AoS, stride 48 B per lane).
-//   mdofmap [ncells][N] int32     : dof index with the Dirichlet flag folded into
-//           the sign bit -- one load instead of a dofmap load plus a dependent
-//           1-byte bc_marker gather per dof (src/laplacian.hpp:182-189).
-//   D       [nd][nd] double       : 1-D derivative table, staged in LDS per block.
+// Work decomposition: cells are grouped into coloured patches (patches.hpp); one
+// workgroup applies the operator to one patch (2x2x2 cells = 1000 threads at
+// P = 4), one thread per (cell, dof).
 //
-// Kernel shape: one thread per (cell, dof); CPB cells per workgroup so that every
-// degree fills >= 4 wavefronts of 64 (the reference launches (P+1)^3 threads per
-// block: 8 threads at P=1).  Element dofs and the three flux components live in
-// LDS; the 1-D contractions read them conflict-free (stride-nd^2/nd/1 reads
-// broadcast within a wave).  Scatter-add uses the hardware FP64 atomic
-// (global_atomic_add_f64; library is built with -munsafe-fp-atomics, the
-// reference is not and gets CAS loops, examples/pmg/CMakeLists.txt:64).
+// HBM layout (owned by the handle):
+//   G      [slot][3][N] double2 : (G00,G01) (G02,G11) (G12,G22) per quadrature
+//          point, slot = patch * K + position in the patch, so a wave reads 1 KiB
+//          contiguous per load instruction (the reference stores [cell][q][6] AoS,
+//          48-byte stride per lane, src/laplacian.hpp:221-227).
+//   pdofs  [poff[p] .. poff[p+1]) uint32 : sorted dofs of patch p, Dirichlet and
+//          "already written" flags in the top bits -- replaces the per-thread
+//          dofmap load + dependent 1-byte bc_marker gather (:182-189) and the
+//          zero-fill of y (:466).
+//   lmaps  [table][K*N] uint16 : position of (cell slot, local dof) in the patch
+//          list; identical patches share one table (a structured box has one
+//          table for all interior patches, so it stays in L2).
+//   D      [nd][nd] double : 1-D derivative table, staged in LDS per workgroup.
+//
+// LDS per workgroup: patch x values, patch y accumulators, element dofs and the
+// three flux components (6 * K*N doubles, 48 KB at P = 4).  The 1-D contractions
+// read LDS conflict-free (the strided index is uniform across most of a wave, so
+// reads broadcast).  Cell contributions are summed with LDS FP64 atomics
+// (ds_add_f64), the global write is a plain store / read-modify-write.
 //
 // Roofline: HBM-bound, AI 0.85 (P=1) .. 2.05 (P=8) flop/B; algorithmic bytes per
-// cell 48N + 4N + 8 + 17U.
+// cell 48N + 4N + 8 + 17U (model "storedG").
 #include "common.hpp"
+#include "patches.hpp"
 
 #include <cmath>
 
@@ -31,7 +39,7 @@ using namespace pmg;
 struct pmg_laplacian_s
 {
   pmg_layout layout = nullptr;
-  int P = 0, nd = 0, N = 0;
+  int P = 0, nd = 0, N = 0, K = 0;
   int32_t ncells = 0, npoints = 0;
   // caller-owned
   const double* kappa = nullptr;
@@ -40,18 +48,25 @@ struct pmg_laplacian_s
   const int32_t* geom_dofmap = nullptr;
   const int8_t* bc = nullptr;
   // owned
-  double2* G = nullptr;
-  int32_t* mdofmap = nullptr;
+  double2* G = nullptr;        // [nslots][3][N]
   double* D = nullptr;         // [nd*nd]
   double* dphi_geom = nullptr; // [3][N][8]
   double* gweights = nullptr;  // [N]
-  int32_t* lcells = nullptr;   // nullptr = identity list 0..n_l-1
-  int32_t* bcells = nullptr;
-  int32_t n_l = 0, n_b = 0;
+  int32_t* pcell = nullptr;    // [npatch*K]
+  int32_t* pncell = nullptr;   // [npatch]
+  int32_t* poff = nullptr;     // [npatch+1]
+  uint32_t* pdofs = nullptr;
+  int32_t* lmap_id = nullptr;  // [npatch]
+  uint16_t* lmaps = nullptr;   // [nuniq][K*N]
+  int32_t npatch = 0;
+  std::vector<int32_t> launch_first, launch_count;
+  int n_launch_l = 0;
+  bool needs_zero = false; // some local dof belongs to no listed cell
   double* diag_inv = nullptr; // [size_local + num_ghosts]
   bool have_diag = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  long long launches = 0; // stiffness-kernel launches since creation
+  long long launches = 0; // full operator applications' kernel launches since creation
+  long long applies = 0;
 };
 
 namespace
@@ -61,9 +76,16 @@ struct Shape
 {
   static constexpr int ND = P + 1;
   static constexpr int N = ND * ND * ND;
-  // cells per workgroup: fill >= 4 waves
-  static constexpr int CPB = P == 1 ? 32 : P == 2 ? 9 : P == 3 ? 4 : P == 4 ? 2 : 1;
-  static constexpr int THREADS = ((CPB * N + 63) / 64) * 64;
+  static constexpr PatchShape PS = patch_shape(P);
+  static constexpr int K = PS.bx * PS.by * PS.bz; // cells per patch
+  static constexpr int CPR = PS.cpr;              // cells per round
+  static constexpr int ROUNDS = K / CPR;
+  static constexpr int MAXM = PS.max_m;           // patch dofs held in LDS
+  static constexpr int RN = CPR * N;              // (cell, dof) pairs per round
+  static constexpr int THREADS = ((RN + 63) / 64) * 64;
+  static constexpr int ITER = (MAXM + THREADS - 1) / THREADS; // gather / store passes
+  static_assert(K % CPR == 0, "rounds must tile the patch");
+  static_assert(MAXM <= 65535, "patch positions are 16-bit");
 };
 
 // ---- geometry: J, adj(J), det at one quadrature point (src/laplacian.hpp:72-97) ----
@@ -102,42 +124,53 @@ __device__ inline void jacobian(const double* __restrict__ xgeom,
   detJ = J[0][0] * K[0][0] + J[0][1] * K[1][0] + J[0][2] * K[2][0];
 }
 
-// G for every (cell, q), paired layout
-__global__ void geometry_kernel(int ncells, int nq, const double* __restrict__ xgeom,
+// G for every (patch slot, q), paired layout
+__global__ void geometry_kernel(long long nslots, int nq, const int32_t* __restrict__ pcell,
+                                const double* __restrict__ xgeom,
                                 const int32_t* __restrict__ geom_dofmap,
                                 const double* __restrict__ dphi, const double* __restrict__ w,
                                 double2* __restrict__ G)
 {
   long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long long)ncells * nq)
+  if (gid >= nslots * nq)
     return;
-  int c = (int)(gid / nq), q = (int)(gid - (long long)c * nq);
-  double K[3][3], detJ;
-  jacobian(xgeom, geom_dofmap + (size_t)c * 8, dphi, nq, q, K, detJ);
-  double s = w[q] / detJ;
-  double g0 = (K[0][0] * K[0][0] + K[0][1] * K[0][1] + K[0][2] * K[0][2]) * s;
-  double g1 = (K[1][0] * K[0][0] + K[1][1] * K[0][1] + K[1][2] * K[0][2]) * s;
-  double g2 = (K[2][0] * K[0][0] + K[2][1] * K[0][1] + K[2][2] * K[0][2]) * s;
-  double g3 = (K[1][0] * K[1][0] + K[1][1] * K[1][1] + K[1][2] * K[1][2]) * s;
-  double g4 = (K[2][0] * K[1][0] + K[2][1] * K[1][1] + K[2][2] * K[1][2]) * s;
-  double g5 = (K[2][0] * K[2][0] + K[2][1] * K[2][1] + K[2][2] * K[2][2]) * s;
-  double2* Gc = G + (size_t)c * 3 * nq;
+  long long slot = gid / nq;
+  int q = (int)(gid - slot * nq);
+  int c = pcell[slot];
+  double g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0;
+  if (c >= 0)
+  {
+    double K[3][3], detJ;
+    jacobian(xgeom, geom_dofmap + (size_t)c * 8, dphi, nq, q, K, detJ);
+    double s = w[q] / detJ;
+    g0 = (K[0][0] * K[0][0] + K[0][1] * K[0][1] + K[0][2] * K[0][2]) * s; // :99-111
+    g1 = (K[1][0] * K[0][0] + K[1][1] * K[0][1] + K[1][2] * K[0][2]) * s;
+    g2 = (K[2][0] * K[0][0] + K[2][1] * K[0][1] + K[2][2] * K[0][2]) * s;
+    g3 = (K[1][0] * K[1][0] + K[1][1] * K[1][1] + K[1][2] * K[1][2]) * s;
+    g4 = (K[2][0] * K[1][0] + K[2][1] * K[1][1] + K[2][2] * K[1][2]) * s;
+    g5 = (K[2][0] * K[2][0] + K[2][1] * K[2][1] + K[2][2] * K[2][2]) * s;
+  }
+  double2* Gc = G + (size_t)slot * 3 * nq;
   Gc[q] = make_double2(g0, g1);
   Gc[nq + q] = make_double2(g2, g3);
   Gc[2 * nq + q] = make_double2(g4, g5);
 }
 
-// paired layout -> the reference's [cell][q][6]
-__global__ void geometry_export_kernel(int ncells, int nq, const double2* __restrict__ G,
-                                       double* __restrict__ out)
+// paired slot layout -> the reference's [cell][q][6]
+__global__ void geometry_export_kernel(long long nslots, int nq, const int32_t* __restrict__ pcell,
+                                       const double2* __restrict__ G, double* __restrict__ out)
 {
   long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long long)ncells * nq)
+  if (gid >= nslots * nq)
     return;
-  int c = (int)(gid / nq), q = (int)(gid - (long long)c * nq);
-  const double2* Gc = G + (size_t)c * 3 * nq;
+  long long slot = gid / nq;
+  int q = (int)(gid - slot * nq);
+  int c = pcell[slot];
+  if (c < 0)
+    return;
+  const double2* Gc = G + (size_t)slot * 3 * nq;
   double2 a = Gc[q], b = Gc[nq + q], d = Gc[2 * nq + q];
-  double* o = out + (size_t)gid * 6;
+  double* o = out + ((size_t)c * nq + q) * 6;
   o[0] = a.x;
   o[1] = a.y;
   o[2] = b.x;
@@ -146,115 +179,198 @@ __global__ void geometry_export_kernel(int ncells, int nq, const double2* __rest
   o[5] = d.y;
 }
 
-__global__ void mask_dofmap_kernel(long long n, const int32_t* __restrict__ dofmap,
-                                   const int8_t* __restrict__ bc, int32_t* __restrict__ out)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
+// the vector-memory counter (s_waitcnt vmcnt(0)), which would stall every wave on
+// the G loads issued at the top of the kernel; nothing in this kernel passes data
+// between threads through global memory, so LDS ordering is all that is needed
+// (cdna_hip_programming.md, "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier()
 {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x)
-  {
-    int32_t d = dofmap[i];
-    out[i] = bc[d] ? (d | (int32_t)0x80000000) : d;
-  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// ---- the hot kernel: y += kappa * B^T G B x over a list of cells ----
+// ---- the hot kernel: y (+)= kappa * B^T G B x over the patches [first, first+gridDim) ----
+//
+// One workgroup per patch.  Phase 0 gathers the patch's x values (and, for dofs an
+// earlier colour already wrote, the y values to accumulate onto) into LDS; then
+// ROUNDS rounds each take CPR cells through the sum-factorised operator and add
+// their contributions into the LDS accumulator; the last phase writes the patch
+// dofs back.  The G stream of round r+1 is issued at the top of round r and stays
+// in flight across the LDS-only barriers.
 template <int P>
 __global__ void __launch_bounds__(Shape<P>::THREADS)
     stiffness_kernel(const double* __restrict__ x, double* __restrict__ y,
-                     const double2* __restrict__ G, const int32_t* __restrict__ mdofmap,
-                     const double* __restrict__ kappa, const int32_t* __restrict__ cells,
-                     int ncells_list, const double* __restrict__ Dg)
+                     const double2* __restrict__ G, const int32_t* __restrict__ poff,
+                     const uint32_t* __restrict__ pdofs, const int32_t* __restrict__ lmap_id,
+                     const uint16_t* __restrict__ lmaps, const int32_t* __restrict__ pcell,
+                     const int32_t* __restrict__ pncell, const double* __restrict__ kappa,
+                     const double* __restrict__ Dg, int first)
 {
-  constexpr int ND = Shape<P>::ND, N = Shape<P>::N, CPB = Shape<P>::CPB, NSQ = ND * ND;
+  using Sh = Shape<P>;
+  constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, CPR = Sh::CPR, ROUNDS = Sh::ROUNDS, NSQ = ND * ND;
+  constexpr int RN = Sh::RN, MAXM = Sh::MAXM, THREADS = Sh::THREADS, ITER = Sh::ITER;
   __shared__ double sD[ND * ND];
-  __shared__ double su[CPB * N];
-  __shared__ double sf0[CPB * N];
-  __shared__ double sf1[CPB * N];
-  __shared__ double sf2[CPB * N];
+  __shared__ double skap[K];
+  __shared__ double sx[MAXM];
+  __shared__ double sy[MAXM];
+  __shared__ double su[RN];
+  __shared__ double sf0[RN];
+  __shared__ double sf1[RN];
+  __shared__ double sf2[RN];
 
+  const int p = first + blockIdx.x;
   const int t = threadIdx.x;
-  const int lc = t / N;
-  const int tl = t - lc * N;
-  const int ci = blockIdx.x * CPB + lc;
-  const bool active = (lc < CPB) && (ci < ncells_list);
+  // wave-uniform patch header: scalar loads
+  const int off = poff[p];
+  const int M = poff[p + 1] - off; // 1 <= M <= MAXM
+  const int table = lmap_id[p];
+  const int nc = pncell[p];
+  const int nrounds = (nc + CPR - 1) / CPR;
 
-  if (t < ND * ND)
-    sD[t] = Dg[t];
+  // position of this thread inside a round
+  const bool inr = t < RN;
+  const int tk = inr ? t : RN - 1;
+  const int lc = tk / N;
+  const int tl = tk - lc * N;
+  const uint16_t* lm = lmaps + (size_t)table * (K * N) + tk;
+  const double2* Gp = G + (size_t)p * K * 3 * N + (size_t)lc * 3 * N + tl;
 
-  int dof = 0;
-  bool is_bc = false;
-  double xo = 0.0, kap = 0.0;
-  double2 g01 = make_double2(0, 0), g23 = g01, g45 = g01;
-  if (active)
+  // ---- phase 0: every load is unconditional (clamped index) so that the compiler
+  // can use counted vmcnt waits; the short loads that feed dependent loads go first.
+  uint32_t m[ITER];
+#pragma unroll
+  for (int k = 0; k < ITER; ++k)
   {
-    const int cell = cells ? cells[ci] : ci;
-    const int32_t m = mdofmap[(size_t)cell * N + tl];
-    const double2* Gc = G + (size_t)cell * 3 * N;
-    g01 = Gc[tl];
-    g23 = Gc[N + tl];
-    g45 = Gc[2 * N + tl];
-    kap = kappa[cell];
-    dof = m & 0x7fffffff;
-    is_bc = m < 0;
-    xo = x[dof];
-    su[lc * N + tl] = is_bc ? 0.0 : xo; // src/laplacian.hpp:186-189
+    const int i = t + k * THREADS;
+    m[k] = pdofs[off + (i < M ? i : M - 1)];
   }
-  __syncthreads();
+  const int cellk = pcell[(size_t)p * K + (t < K ? t : K - 1)];
+  const double dval = Dg[t < ND * ND ? t : ND * ND - 1];
+  double xv[ITER], yv[ITER];
+#pragma unroll
+  for (int k = 0; k < ITER; ++k)
+  {
+    const uint32_t dof = m[k] & PD_MASK;
+    const bool acc = (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+    xv[k] = x[dof];
+    const double* ya = acc ? (const double*)(y + dof) : (x + dof); // re-read of x keeps it unconditional
+    yv[k] = *ya;
+  }
+  const double kapk = kappa[cellk >= 0 ? cellk : 0];
+  // round 0 operands
+  int l_nxt = lm[0];
+  double2 g01_nxt = Gp[0], g23_nxt = Gp[N], g45_nxt = Gp[2 * N]; // empty slots hold zeros
+
+#pragma unroll
+  for (int k = 0; k < ITER; ++k)
+  {
+    const int i = t + k * THREADS;
+    if (i < M)
+    {
+      const bool acc = (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+      sx[i] = (m[k] & PD_BC) ? 0.0 : xv[k]; // Dirichlet columns masked, src/laplacian.hpp:186-189
+      sy[i] = acc ? yv[k] : 0.0;
+    }
+  }
+  if (t < ND * ND)
+    sD[t] = dval;
+  if (t < K)
+    skap[t] = kapk;
+  lds_barrier();
 
   const int a = tl / NSQ;
   const int b = (tl - a * NSQ) / ND;
   const int c = tl - a * NSQ - b * ND;
-  double val = 0.0;
-  if (active)
-  {
-    const double* u = su + lc * N;
-    double vx = 0.0, vy = 0.0, vz = 0.0;
+
 #pragma unroll
-    for (int i = 0; i < ND; ++i)
+  for (int r = 0; r < ROUNDS; ++r)
+  {
+    if (r >= nrounds)
+      break;
+    const int l = l_nxt;
+    const double2 g01 = g01_nxt, g23 = g23_nxt, g45 = g45_nxt;
+    if (r + 1 < ROUNDS) // compile-time after unrolling: stream the next round's operands
     {
-      vx += sD[a * ND + i] * u[i * NSQ + b * ND + c]; // :195-199
-      vy += sD[b * ND + i] * u[a * NSQ + i * ND + c]; // :206-210
-      vz += sD[c * ND + i] * u[a * NSQ + b * ND + i]; // :214-218
+      l_nxt = lm[(r + 1) * RN];
+      g01_nxt = Gp[(size_t)(r + 1) * CPR * 3 * N];
+      g23_nxt = Gp[(size_t)(r + 1) * CPR * 3 * N + N];
+      g45_nxt = Gp[(size_t)(r + 1) * CPR * 3 * N + 2 * N];
     }
-    sf0[lc * N + tl] = kap * (g01.x * vx + g01.y * vy + g23.x * vz); // :233
-    sf1[lc * N + tl] = kap * (g01.y * vx + g23.y * vy + g45.x * vz); // :234
-    sf2[lc * N + tl] = kap * (g23.x * vx + g45.x * vy + g45.y * vz); // :235
+    const bool active = inr && (r * CPR + lc < nc);
+    if (active)
+      su[t] = sx[l];
+    lds_barrier();
+    if (active)
+    {
+      const double kap = skap[r * CPR + lc];
+      const double* u = su + lc * N;
+      double vx = 0.0, vy = 0.0, vz = 0.0;
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+      {
+        vx += sD[a * ND + i] * u[i * NSQ + b * ND + c]; // :195-199
+        vy += sD[b * ND + i] * u[a * NSQ + i * ND + c]; // :206-210
+        vz += sD[c * ND + i] * u[a * NSQ + b * ND + i]; // :214-218
+      }
+      sf0[t] = kap * (g01.x * vx + g01.y * vy + g23.x * vz); // :233
+      sf1[t] = kap * (g01.y * vx + g23.y * vy + g45.x * vz); // :234
+      sf2[t] = kap * (g23.x * vx + g45.x * vy + g45.y * vz); // :235
+    }
+    lds_barrier();
+    if (active)
+    {
+      const double* f0 = sf0 + lc * N;
+      const double* f1 = sf1 + lc * N;
+      const double* f2 = sf2 + lc * N;
+      double wx = 0.0, wy = 0.0, wz = 0.0;
+#pragma unroll
+      for (int q = 0; q < ND; ++q)
+      {
+        wx += sD[q * ND + a] * f0[q * NSQ + b * ND + c]; // :246-251
+        wy += sD[q * ND + b] * f1[a * NSQ + q * ND + c]; // :255-259
+        wz += sD[q * ND + c] * f2[a * NSQ + b * ND + q]; // :263-267
+      }
+      atomicAdd(&sy[l], wx + wy + wz); // :270,277 -- in LDS (ds_add_f64)
+    }
   }
-  __syncthreads();
-  if (active)
-  {
-    const double* f0 = sf0 + lc * N;
-    const double* f1 = sf1 + lc * N;
-    const double* f2 = sf2 + lc * N;
-    double wx = 0.0, wy = 0.0, wz = 0.0;
+  lds_barrier();
+
+  // ---- write back: plain stores (the accumulator started from the earlier colours' y)
 #pragma unroll
-    for (int q = 0; q < ND; ++q)
+  for (int k = 0; k < ITER; ++k)
+  {
+    const int i = t + k * THREADS;
+    if (i < M)
     {
-      wx += sD[q * ND + a] * f0[q * NSQ + b * ND + c]; // :246-251
-      wy += sD[q * ND + b] * f1[a * NSQ + q * ND + c]; // :255-259
-      wz += sD[q * ND + c] * f2[a * NSQ + b * ND + q]; // :263-267
+      const uint32_t dof = m[k] & PD_MASK;
+      if (m[k] & PD_BC)
+      {
+        if (!(m[k] & PD_ACC))
+          y[dof] = xv[k]; // :273-274
+      }
+      else
+        y[dof] = sy[i];
     }
-    val = wx + wy + wz; // :270
-    if (is_bc)
-      y[dof] = xo; // :273-274 (every sharing cell stores the same value)
-    else
-      atomicAdd(&y[dof], val); // :277, global_atomic_add_f64
   }
 }
 
 // ---- matrix-free diagonal (replaces the CSR detour of examples/pmg/main.cpp:274-279) ----
-__global__ void diagonal_kernel(int ncells, int nd, const double2* __restrict__ G,
-                                const int32_t* __restrict__ mdofmap,
-                                const double* __restrict__ kappa, const double* __restrict__ D,
-                                double* __restrict__ diag)
+__global__ void diagonal_kernel(long long nslots, int nd, const int32_t* __restrict__ pcell,
+                                const double2* __restrict__ G, const int32_t* __restrict__ dofmap,
+                                const int8_t* __restrict__ bc, const double* __restrict__ kappa,
+                                const double* __restrict__ D, double* __restrict__ diag)
 {
   const int N = nd * nd * nd, nsq = nd * nd;
   long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long long)ncells * N)
+  if (gid >= nslots * N)
     return;
-  int cell = (int)(gid / N), t = (int)(gid - (long long)cell * N);
+  long long slot = gid / N;
+  int t = (int)(gid - slot * N);
+  int cell = pcell[slot];
+  if (cell < 0)
+    return;
   int a = t / nsq, b = (t - a * nsq) / nd, c = t - a * nsq - b * nd;
-  const double2* Gc = G + (size_t)cell * 3 * N;
+  const double2* Gc = G + (size_t)slot * 3 * N;
   double s = 0.0;
   for (int q = 0; q < nd; ++q)
   {
@@ -265,9 +381,9 @@ __global__ void diagonal_kernel(int ncells, int nd, const double2* __restrict__ 
   }
   double daa = D[a * nd + a], dbb = D[b * nd + b], dcc = D[c * nd + c];
   s += 2.0 * (Gc[t].y * daa * dbb + Gc[N + t].x * daa * dcc + Gc[2 * N + t].x * dbb * dcc);
-  int32_t m = mdofmap[(size_t)cell * N + t];
-  if (m >= 0)
-    atomicAdd(&diag[m], kappa[cell] * s);
+  int32_t dof = dofmap[(size_t)cell * N + t];
+  if (!bc[dof])
+    atomicAdd(&diag[dof], kappa[cell] * s);
 }
 
 __global__ void diag_invert_kernel(int n, const int8_t* __restrict__ bc, double* __restrict__ d)
@@ -281,63 +397,81 @@ __global__ void diag_invert_kernel(int n, const int8_t* __restrict__ bc, double*
 }
 
 // ---- GLL-collocated load vector ----
-__global__ void rhs_kernel(int ncells, int nq, const double* __restrict__ xgeom,
+__global__ void rhs_kernel(long long nslots, int nq, const int32_t* __restrict__ pcell,
+                           const double* __restrict__ xgeom,
                            const int32_t* __restrict__ geom_dofmap,
                            const double* __restrict__ dphi, const double* __restrict__ w,
-                           const int32_t* __restrict__ mdofmap, const double* __restrict__ kappa,
-                           const double* __restrict__ f, double* __restrict__ b)
+                           const int32_t* __restrict__ dofmap, const int8_t* __restrict__ bc,
+                           const double* __restrict__ kappa, const double* __restrict__ f,
+                           double* __restrict__ b)
 {
   long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long long)ncells * nq)
+  if (gid >= nslots * nq)
     return;
-  int c = (int)(gid / nq), q = (int)(gid - (long long)c * nq);
-  int32_t m = mdofmap[gid];
-  if (m < 0)
+  long long slot = gid / nq;
+  int q = (int)(gid - slot * nq);
+  int c = pcell[slot];
+  if (c < 0)
+    return;
+  int32_t dof = dofmap[(size_t)c * nq + q];
+  if (bc[dof])
     return; // set_bc: b[bc] = 0 (b is zeroed first)
   double K[3][3], detJ;
   jacobian(xgeom, geom_dofmap + (size_t)c * 8, dphi, nq, q, K, detJ);
-  atomicAdd(&b[m], kappa[c] * w[q] * detJ * f[m]);
+  atomicAdd(&b[dof], kappa[c] * w[q] * detJ * f[dof]);
 }
 
 template <int P>
-int launch_stiffness(pmg_laplacian op, const double* x, double* y, const int32_t* cells, int n,
+int launch_stiffness(pmg_laplacian op, const double* x, double* y, int first, int count,
                      hipStream_t s)
 {
-  if (n <= 0)
+  if (count <= 0)
     return PMG_OK;
-  constexpr int CPB = Shape<P>::CPB;
-  int grid = (n + CPB - 1) / CPB;
-  stiffness_kernel<P><<<grid, Shape<P>::THREADS, 0, s>>>(x, y, op->G, op->mdofmap, op->kappa,
-                                                         cells, n, op->D);
+  stiffness_kernel<P><<<count, Shape<P>::THREADS, 0, s>>>(x, y, op->G, op->poff, op->pdofs,
+                                                          op->lmap_id, op->lmaps, op->pcell,
+                                                          op->pncell, op->kappa, op->D, first);
   op->launches++;
-  PMG_HIP(hipGetLastError());
   return PMG_OK;
 }
 
-int dispatch_stiffness(pmg_laplacian op, const double* x, double* y, const int32_t* cells, int n,
-                       hipStream_t s)
+// launches [l0, l1) of the plan, in stream order
+int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, hipStream_t s)
 {
-  switch (op->P)
+  for (int l = l0; l < l1; ++l)
   {
-  case 1:
-    return launch_stiffness<1>(op, x, y, cells, n, s);
-  case 2:
-    return launch_stiffness<2>(op, x, y, cells, n, s);
-  case 3:
-    return launch_stiffness<3>(op, x, y, cells, n, s);
-  case 4:
-    return launch_stiffness<4>(op, x, y, cells, n, s);
-  case 5:
-    return launch_stiffness<5>(op, x, y, cells, n, s);
-  case 6:
-    return launch_stiffness<6>(op, x, y, cells, n, s);
-  case 7:
-    return launch_stiffness<7>(op, x, y, cells, n, s);
-  case 8:
-    return launch_stiffness<8>(op, x, y, cells, n, s);
-  default:
-    return fail(PMG_ERR_INVALID, "Unsupported degree"); // src/laplacian.hpp:346,479
+    const int first = op->launch_first[l], count = op->launch_count[l];
+    switch (op->P)
+    {
+    case 1:
+      PMG_TRY(launch_stiffness<1>(op, x, y, first, count, s));
+      break;
+    case 2:
+      PMG_TRY(launch_stiffness<2>(op, x, y, first, count, s));
+      break;
+    case 3:
+      PMG_TRY(launch_stiffness<3>(op, x, y, first, count, s));
+      break;
+    case 4:
+      PMG_TRY(launch_stiffness<4>(op, x, y, first, count, s));
+      break;
+    case 5:
+      PMG_TRY(launch_stiffness<5>(op, x, y, first, count, s));
+      break;
+    case 6:
+      PMG_TRY(launch_stiffness<6>(op, x, y, first, count, s));
+      break;
+    case 7:
+      PMG_TRY(launch_stiffness<7>(op, x, y, first, count, s));
+      break;
+    case 8:
+      PMG_TRY(launch_stiffness<8>(op, x, y, first, count, s));
+      break;
+    default:
+      return fail(PMG_ERR_INVALID, "Unsupported degree"); // src/laplacian.hpp:346,479
+    }
   }
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
 }
 
 template <typename T>
@@ -348,6 +482,8 @@ int upload(T** dst, const T* src, size_t n, hipStream_t s)
     PMG_HIP(hipMemcpyAsync(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice, s));
   return PMG_OK;
 }
+
+static_assert(Shape<4>::K == 32 && Shape<4>::ROUNDS == 8 && Shape<4>::THREADS == 512, "P = 4 patch");
 } // namespace
 
 namespace pmg
@@ -356,17 +492,20 @@ namespace pmg
 int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s);
 const double* laplacian_diag_inv(pmg_laplacian op) { return op->diag_inv; }
 pmg_layout laplacian_layout(pmg_laplacian op) { return op->layout; }
-long long laplacian_launches(pmg_laplacian op) { return op->launches; }
+long long laplacian_launches(pmg_laplacian op) { return op->applies; }
 
 // operator()(in, out), src/laplacian.hpp:462-482 + impl_operator :373-460
 int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s)
 {
   pmg_layout l = op->layout;
-  PMG_HIP(hipMemsetAsync(out, 0, sizeof(double) * l->total(), s)); // :466
-  PMG_TRY(pmg_scatter_fwd_begin(l, in, (pmg_stream)s));           // :378
-  PMG_TRY(dispatch_stiffness(op, in, out, op->lcells, op->n_l, s)); // :380-413
-  PMG_TRY(pmg_scatter_fwd_end(l, in, (pmg_stream)s));             // :425
-  PMG_TRY(dispatch_stiffness(op, in, out, op->bcells, op->n_b, s)); // :429-455
+  const int nl = (int)op->launch_first.size();
+  if (op->needs_zero || nl == 0)
+    PMG_HIP(hipMemsetAsync(out, 0, sizeof(double) * l->total(), s)); // :466 (else: first-writer stores)
+  PMG_TRY(pmg_scatter_fwd_begin(l, in, (pmg_stream)s));          // :378
+  PMG_TRY(run_launches(op, in, out, 0, op->n_launch_l, s));      // :380-413 interior cells
+  PMG_TRY(pmg_scatter_fwd_end(l, in, (pmg_stream)s));            // :425
+  PMG_TRY(run_launches(op, in, out, op->n_launch_l, nl, s));     // :429-455 boundary cells
+  op->applies++;
   return PMG_OK;
 }
 } // namespace pmg
@@ -387,10 +526,22 @@ extern "C" int pmg_laplacian_create_with_tables(
               "pmg_laplacian_create: NULL array");
   PMG_REQUIRE((n_lcells == 0 || lcells) && (n_bcells == 0 || bcells),
               "pmg_laplacian_create: NULL cell list");
-  for (int i = 0; i < n_lcells; ++i)
-    PMG_REQUIRE(lcells[i] >= 0 && lcells[i] < ncells, "pmg_laplacian_create: lcells[%d] = %d out of range", i, lcells[i]);
-  for (int i = 0; i < n_bcells; ++i)
-    PMG_REQUIRE(bcells[i] >= 0 && bcells[i] < ncells, "pmg_laplacian_create: bcells[%d] = %d out of range", i, bcells[i]);
+  PMG_REQUIRE(npoints >= 0, "pmg_laplacian_create: negative npoints");
+  {
+    std::vector<char> seen(ncells, 0);
+    for (int set = 0; set < 2; ++set)
+    {
+      const int32_t* list = set ? bcells : lcells;
+      const int n = set ? n_bcells : n_lcells;
+      for (int i = 0; i < n; ++i)
+      {
+        PMG_REQUIRE(list[i] >= 0 && list[i] < ncells,
+                    "pmg_laplacian_create: cell list entry %d out of range", list[i]);
+        PMG_REQUIRE(!seen[list[i]], "pmg_laplacian_create: cell %d listed twice", list[i]);
+        seen[list[i]] = 1;
+      }
+    }
+  }
 
   hipStream_t s = S(stream);
   auto* op = new pmg_laplacian_s;
@@ -398,6 +549,12 @@ extern "C" int pmg_laplacian_create_with_tables(
   op->P = degree;
   op->nd = degree + 1;
   op->N = op->nd * op->nd * op->nd;
+  op->K = patch_shape(degree).K();
+  {
+    const int kk[9] = {0, Shape<1>::K, Shape<2>::K, Shape<3>::K, Shape<4>::K, Shape<5>::K,
+                       Shape<6>::K, Shape<7>::K, Shape<8>::K};
+    PMG_REQUIRE(kk[degree] == op->K, "internal: patch shape / kernel shape mismatch");
+  }
   op->ncells = ncells;
   op->npoints = npoints;
   op->kappa = kappa;
@@ -406,6 +563,7 @@ extern "C" int pmg_laplacian_create_with_tables(
   op->geom_dofmap = geom_dofmap;
   op->bc = bc_marker;
   const int nd = op->nd, N = op->N;
+  const int total = layout->total();
 
   // 1-D tables (basix's job in the reference, src/laplacian.hpp:302-317)
   std::vector<double> pts(nd), wts(nd), D(nd * nd);
@@ -449,33 +607,67 @@ extern "C" int pmg_laplacian_create_with_tables(
     PMG_HIP(hipStreamSynchronize(s)); // host vectors go out of scope
   }
 
-  // cell lists; an identity list (single rank: every cell is "local") needs no indirection
-  bool identity = (n_lcells == ncells);
-  for (int i = 0; identity && i < n_lcells; ++i)
-    identity = (lcells[i] == i);
-  op->n_l = n_lcells;
-  op->n_b = n_bcells;
-  if (!identity && n_lcells > 0)
-    PMG_TRY(upload(&op->lcells, lcells, n_lcells, s));
-  if (n_bcells > 0)
-    PMG_TRY(upload(&op->bcells, bcells, n_bcells, s));
+  // ---- patches (host): needs the dofmap, the Dirichlet marker and cell centroids ----
+  PatchPlan plan;
+  {
+    std::vector<int32_t> h_dofmap((size_t)ncells * N), h_gd((size_t)ncells * 8);
+    std::vector<int8_t> h_bc(total);
+    std::vector<double> h_x((size_t)npoints * 3);
+    PMG_HIP(hipMemcpyAsync(h_dofmap.data(), dofmap, sizeof(int32_t) * h_dofmap.size(),
+                           hipMemcpyDeviceToHost, s));
+    PMG_HIP(hipMemcpyAsync(h_gd.data(), geom_dofmap, sizeof(int32_t) * h_gd.size(),
+                           hipMemcpyDeviceToHost, s));
+    PMG_HIP(hipMemcpyAsync(h_bc.data(), bc_marker, sizeof(int8_t) * h_bc.size(),
+                           hipMemcpyDeviceToHost, s));
+    PMG_HIP(hipMemcpyAsync(h_x.data(), xgeom, sizeof(double) * h_x.size(), hipMemcpyDeviceToHost, s));
+    PMG_HIP(hipStreamSynchronize(s));
+    std::vector<float> centroid((size_t)ncells * 3);
+    for (int32_t c = 0; c < ncells; ++c)
+      for (int a = 0; a < 3; ++a)
+      {
+        double v = 0;
+        for (int k = 0; k < 8; ++k)
+        {
+          int32_t g = h_gd[(size_t)c * 8 + k];
+          PMG_REQUIRE(g >= 0 && g < npoints, "pmg_laplacian_create: geometry dofmap entry %d out of range", g);
+          v += h_x[3 * (size_t)g + a];
+        }
+        centroid[(size_t)c * 3 + a] = (float)(v * 0.125);
+      }
+    PMG_TRY(build_patch_plan(plan, degree, ncells, h_dofmap.data(), h_bc.data(), total,
+                             centroid.data(), lcells, n_lcells, bcells, n_bcells));
+    // is every local dof written by some patch?  (else out must be zero-filled first)
+    std::vector<char> touched(total, 0);
+    for (uint32_t v : plan.pdofs)
+      touched[v & PD_MASK] = 1;
+    for (int i = 0; i < total && !op->needs_zero; ++i)
+      op->needs_zero = !touched[i];
+  }
+  op->npatch = plan.npatch;
+  op->launch_first = plan.launch_first;
+  op->launch_count = plan.launch_count;
+  op->n_launch_l = plan.n_launch_l;
+  PMG_TRY(upload(&op->pcell, plan.pcell.data(), plan.pcell.size(), s));
+  PMG_TRY(upload(&op->pncell, plan.pncell.data(), plan.pncell.size(), s));
+  PMG_TRY(upload(&op->poff, plan.poff.data(), plan.poff.size(), s));
+  PMG_TRY(upload(&op->pdofs, plan.pdofs.data(), plan.pdofs.size(), s));
+  PMG_TRY(upload(&op->lmap_id, plan.lmap_id.data(), plan.lmap_id.size(), s));
+  PMG_TRY(upload(&op->lmaps, plan.lmaps.data(), plan.lmaps.size(), s));
 
-  const long long nq_total = (long long)ncells * N;
+  const long long nslots = (long long)plan.npatch * op->K;
+  const long long nq_total = nslots * N;
   PMG_HIP(hipMalloc(&op->G, sizeof(double2) * 3 * (nq_total ? nq_total : 1)));
-  PMG_HIP(hipMalloc(&op->mdofmap, sizeof(int32_t) * (nq_total ? nq_total : 1)));
-  PMG_HIP(hipMalloc(&op->diag_inv, sizeof(double) * (layout->total() ? layout->total() : 1)));
+  PMG_HIP(hipMalloc(&op->diag_inv, sizeof(double) * (total ? total : 1)));
   PMG_HIP(hipEventCreate(&op->ev0));
   PMG_HIP(hipEventCreate(&op->ev1));
   if (nq_total > 0)
   {
-    int blocks = (int)((nq_total + 255) / 256);
-    geometry_kernel<<<blocks, 256, 0, s>>>(ncells, N, xgeom, geom_dofmap, op->dphi_geom,
-                                          op->gweights, op->G);
-    mask_dofmap_kernel<<<blocks > 4096 ? 4096 : blocks, 256, 0, s>>>(nq_total, dofmap, bc_marker,
-                                                                   op->mdofmap);
+    long long blocks = (nq_total + 255) / 256;
+    geometry_kernel<<<(unsigned)blocks, 256, 0, s>>>(nslots, N, op->pcell, xgeom, geom_dofmap,
+                                                    op->dphi_geom, op->gweights, op->G);
     PMG_HIP(hipGetLastError());
   }
-  PMG_HIP(hipStreamSynchronize(s)); // host cell lists may be freed by the caller
+  PMG_HIP(hipStreamSynchronize(s)); // plan's host vectors are released on return
   *out = op;
   return PMG_OK;
 }
@@ -497,12 +689,15 @@ extern "C" int pmg_laplacian_destroy(pmg_laplacian op)
   if (!op)
     return PMG_OK;
   (void)hipFree(op->G);
-  (void)hipFree(op->mdofmap);
   (void)hipFree(op->D);
   (void)hipFree(op->dphi_geom);
   (void)hipFree(op->gweights);
-  (void)hipFree(op->lcells);
-  (void)hipFree(op->bcells);
+  (void)hipFree(op->pcell);
+  (void)hipFree(op->pncell);
+  (void)hipFree(op->poff);
+  (void)hipFree(op->pdofs);
+  (void)hipFree(op->lmap_id);
+  (void)hipFree(op->lmaps);
   (void)hipFree(op->diag_inv);
   if (op->ev0)
     (void)hipEventDestroy(op->ev0);
@@ -547,10 +742,12 @@ extern "C" int pmg_laplacian_compute_diag_inverse(pmg_laplacian op, pmg_stream s
   hipStream_t s = S(stream);
   const int total = op->layout->total();
   PMG_HIP(hipMemsetAsync(op->diag_inv, 0, sizeof(double) * total, s));
-  const long long n = (long long)op->ncells * op->N;
+  const long long nslots = (long long)op->npatch * op->K;
+  const long long n = nslots * op->N;
   if (n > 0)
-    diagonal_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(op->ncells, op->nd, op->G, op->mdofmap,
-                                                          op->kappa, op->D, op->diag_inv);
+    diagonal_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(nslots, op->nd, op->pcell, op->G,
+                                                               op->dofmap, op->bc, op->kappa,
+                                                               op->D, op->diag_inv);
   if (total > 0)
     diag_invert_kernel<<<(total + 255) / 256, 256, 0, s>>>(total, op->bc, op->diag_inv);
   PMG_HIP(hipGetLastError());
@@ -561,10 +758,13 @@ extern "C" int pmg_laplacian_compute_diag_inverse(pmg_laplacian op, pmg_stream s
 extern "C" int pmg_laplacian_get_geometry(pmg_laplacian op, double* G_out, pmg_stream stream)
 {
   PMG_REQUIRE(op && G_out, "pmg_laplacian_get_geometry: NULL argument");
-  const long long n = (long long)op->ncells * op->N;
+  hipStream_t s = S(stream);
+  PMG_HIP(hipMemsetAsync(G_out, 0, sizeof(double) * 6 * (size_t)op->ncells * op->N, s));
+  const long long nslots = (long long)op->npatch * op->K;
+  const long long n = nslots * op->N;
   if (n > 0)
-    geometry_export_kernel<<<(int)((n + 255) / 256), 256, 0, S(stream)>>>(op->ncells, op->N, op->G,
-                                                                         G_out);
+    geometry_export_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(nslots, op->N, op->pcell,
+                                                                      op->G, G_out);
   PMG_HIP(hipGetLastError());
   return PMG_OK;
 }
@@ -575,11 +775,13 @@ extern "C" int pmg_laplacian_assemble_rhs(pmg_laplacian op, const double* f, dou
   PMG_REQUIRE(op && f && b, "pmg_laplacian_assemble_rhs: NULL argument");
   hipStream_t s = S(stream);
   PMG_HIP(hipMemsetAsync(b, 0, sizeof(double) * op->layout->total(), s));
-  const long long n = (long long)op->ncells * op->N;
+  const long long nslots = (long long)op->npatch * op->K;
+  const long long n = nslots * op->N;
   if (n > 0)
-    rhs_kernel<<<(int)((n + 255) / 256), 256, 0, s>>>(op->ncells, op->N, op->xgeom,
-                                                     op->geom_dofmap, op->dphi_geom, op->gweights,
-                                                     op->mdofmap, op->kappa, f, b);
+    rhs_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(nslots, op->N, op->pcell, op->xgeom,
+                                                          op->geom_dofmap, op->dphi_geom,
+                                                          op->gweights, op->dofmap, op->bc,
+                                                          op->kappa, f, b);
   PMG_HIP(hipGetLastError());
   return PMG_OK;
 }
@@ -587,19 +789,26 @@ extern "C" int pmg_laplacian_assemble_rhs(pmg_laplacian op, const double* f, dou
 extern "C" int pmg_laplacian_time_kernel(pmg_laplacian op, const double* in, double* out, int reps,
                                          double* ms_per_launch, pmg_stream stream)
 {
-  PMG_REQUIRE(op && in && out && ms_per_launch && reps > 0, "pmg_laplacian_time_kernel: bad argument");
+  PMG_REQUIRE(op && in && out && ms_per_launch && reps > 0,
+              "pmg_laplacian_time_kernel: bad argument");
   hipStream_t s = S(stream);
-  // every local cell in one launch each, exactly the kernel the apply issues
+  const int nl = (int)op->launch_first.size();
+  PMG_REQUIRE(nl > 0, "pmg_laplacian_time_kernel: operator has no cells");
+  // every launch of one operator application (all colours, both cell lists),
+  // exactly the kernels pmg_laplacian_apply issues, without halo or zero-fill
   PMG_HIP(hipEventRecord(op->ev0, s));
   for (int r = 0; r < reps; ++r)
-  {
-    PMG_TRY(dispatch_stiffness(op, in, out, op->lcells, op->n_l, s));
-    PMG_TRY(dispatch_stiffness(op, in, out, op->bcells, op->n_b, s));
-  }
+    PMG_TRY(run_launches(op, in, out, 0, nl, s));
   PMG_HIP(hipEventRecord(op->ev1, s));
   PMG_HIP(hipEventSynchronize(op->ev1));
   float ms = 0.f;
   PMG_HIP(hipEventElapsedTime(&ms, op->ev0, op->ev1));
-  *ms_per_launch = (double)ms / reps;
+  *ms_per_launch = (double)ms / reps / nl;
   return PMG_OK;
+}
+
+// number of stiffness-kernel launches one operator application issues
+extern "C" int pmg_laplacian_launches_per_apply(pmg_laplacian op)
+{
+  return op ? (int)op->launch_first.size() : -1;
 }

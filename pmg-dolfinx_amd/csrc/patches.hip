@@ -1,0 +1,326 @@
+// Host-side construction of the cell patches (see patches.hpp).  Set-up only.
+#include "patches.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <numeric>
+
+namespace pmg
+{
+namespace
+{
+// Rank transform of one coordinate: cluster values closer than tol, return the
+// cluster index of every entry and the number of clusters.
+int rank_axis(const std::vector<float>& v, float tol, std::vector<int32_t>& idx)
+{
+  const size_t n = v.size();
+  std::vector<int32_t> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return v[a] < v[b]; });
+  idx.assign(n, 0);
+  int ncl = 0;
+  float last = 0.f;
+  for (size_t i = 0; i < n; ++i)
+  {
+    float x = v[order[i]];
+    if (i == 0 || x - last > tol)
+    {
+      ++ncl;
+      last = x;
+    }
+    idx[order[i]] = ncl - 1;
+  }
+  return ncl;
+}
+
+inline uint64_t spread3(uint32_t v) // 21 bits -> every third bit
+{
+  uint64_t x = v & 0x1fffff;
+  x = (x | x << 32) & 0x1f00000000ffffULL;
+  x = (x | x << 16) & 0x1f0000ff0000ffULL;
+  x = (x | x << 8) & 0x100f00f00f00f00fULL;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ULL;
+  x = (x | x << 2) & 0x1249249249249249ULL;
+  return x;
+}
+
+// Group the cells of one list into patches of <= K cells; returns groups of cell ids.
+void group_cells(const int32_t* cells, int32_t n, const float* centroid, PatchShape shp,
+                 std::vector<std::vector<int32_t>>& groups)
+{
+  groups.clear();
+  if (n == 0)
+    return;
+  const int K = shp.K();
+  if (K == 1)
+  {
+    for (int32_t i = 0; i < n; ++i)
+      groups.push_back({cells[i]});
+    return;
+  }
+  std::vector<float> c[3];
+  float lo[3], hi[3];
+  for (int a = 0; a < 3; ++a)
+  {
+    c[a].resize(n);
+    lo[a] = 1e30f;
+    hi[a] = -1e30f;
+    for (int32_t i = 0; i < n; ++i)
+    {
+      float x = centroid[3 * (size_t)cells[i] + a];
+      c[a][i] = x;
+      lo[a] = std::min(lo[a], x);
+      hi[a] = std::max(hi[a], x);
+    }
+  }
+  // tensor-grid detection: few distinct centroid coordinates per axis
+  std::vector<int32_t> gi[3];
+  int ncl[3];
+  bool tensor = true;
+  double cap = 4.0 * std::cbrt((double)n) + 8.0;
+  for (int a = 0; a < 3; ++a)
+  {
+    float ext = std::max(hi[a] - lo[a], 1e-30f);
+    ncl[a] = rank_axis(c[a], 1e-5f * ext, gi[a]);
+    if (ncl[a] > cap * 4)
+      tensor = false;
+  }
+  if (tensor && (double)ncl[0] * ncl[1] * ncl[2] > 64.0 * n + 4096.0)
+    tensor = false;
+
+  std::vector<int32_t> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  if (tensor)
+  {
+    // sort by (block key, position inside the block); equal keys form a patch
+    std::vector<uint64_t> key(n);
+    for (int32_t i = 0; i < n; ++i)
+    {
+      uint64_t bx = gi[0][i] / shp.bx, by = gi[1][i] / shp.by, bz = gi[2][i] / shp.bz;
+      key[i] = (bx << 42) | (by << 21) | bz;
+    }
+    std::sort(order.begin(), order.end(),
+              [&](int32_t a, int32_t b)
+              {
+                if (key[a] != key[b])
+                  return key[a] < key[b];
+                // z-layer major inside a block: a round of the kernel takes one layer
+                if (gi[2][a] != gi[2][b])
+                  return gi[2][a] < gi[2][b];
+                if (gi[0][a] != gi[0][b])
+                  return gi[0][a] < gi[0][b];
+                return gi[1][a] < gi[1][b];
+              });
+    for (int32_t i = 0; i < n;)
+    {
+      int32_t j = i;
+      std::vector<int32_t> g;
+      while (j < n && key[order[j]] == key[order[i]] && (int)g.size() < K)
+        g.push_back(cells[order[j++]]);
+      groups.push_back(std::move(g));
+      i = j;
+    }
+  }
+  else
+  {
+    // Morton order of the quantised centroids, chunks of K
+    std::vector<uint64_t> key(n);
+    for (int32_t i = 0; i < n; ++i)
+    {
+      uint64_t k = 0;
+      for (int a = 0; a < 3; ++a)
+      {
+        float ext = std::max(hi[a] - lo[a], 1e-30f);
+        uint32_t q = (uint32_t)std::min(2097151.0f, (c[a][i] - lo[a]) / ext * 2097151.0f);
+        k |= spread3(q) << (2 - a);
+      }
+      key[i] = k;
+    }
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+    for (int32_t i = 0; i < n; i += K)
+    {
+      std::vector<int32_t> g;
+      for (int32_t j = i; j < n && j < i + K; ++j)
+        g.push_back(cells[order[j]]);
+      groups.push_back(std::move(g));
+    }
+  }
+}
+} // namespace
+
+int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofmap,
+                     const int8_t* bc, int32_t ndofs, const float* centroid,
+                     const int32_t* lcells, int32_t n_l, const int32_t* bcells, int32_t n_b)
+{
+  const PatchShape shp = patch_shape(P);
+  const int K = shp.K();
+  const int nd = P + 1, N = nd * nd * nd;
+  plan = PatchPlan();
+  plan.K = K;
+  plan.N = N;
+
+  struct Tmp
+  {
+    std::vector<int32_t> cells;
+    std::vector<int32_t> dofs; // sorted unique
+    std::vector<uint16_t> lmap;
+    int colour = 0;
+    int launch = 0;
+  };
+  std::vector<Tmp> tmp;
+  int set_first[3] = {0, 0, 0};
+  for (int set = 0; set < 2; ++set)
+  {
+    std::vector<std::vector<int32_t>> groups;
+    group_cells(set == 0 ? lcells : bcells, set == 0 ? n_l : n_b, centroid, shp, groups);
+    // a group whose cells have more than max_m distinct dofs (irregular meshes,
+    // Morton chunks) is halved until it fits the kernel's LDS capacity
+    std::vector<std::vector<int32_t>> work(groups.rbegin(), groups.rend());
+    std::vector<int32_t> scratch;
+    while (!work.empty())
+    {
+      std::vector<int32_t> g = std::move(work.back());
+      work.pop_back();
+      scratch.clear();
+      for (int32_t cell : g)
+      {
+        if (cell < 0 || cell >= ncells)
+          return fail(PMG_ERR_INVALID, "cell %d out of range", cell);
+        scratch.insert(scratch.end(), dofmap + (size_t)cell * N, dofmap + (size_t)(cell + 1) * N);
+      }
+      std::sort(scratch.begin(), scratch.end());
+      size_t m = std::unique(scratch.begin(), scratch.end()) - scratch.begin();
+      if ((int)m > shp.max_m && g.size() > 1)
+      {
+        size_t h = g.size() / 2;
+        work.emplace_back(g.begin() + h, g.end());
+        work.emplace_back(g.begin(), g.begin() + h);
+        continue;
+      }
+      if ((int)m > shp.max_m)
+        return fail(PMG_ERR_INVALID, "internal: one cell exceeds the patch capacity");
+      Tmp t;
+      t.cells = std::move(g);
+      tmp.push_back(std::move(t));
+    }
+    set_first[set + 1] = (int)tmp.size();
+  }
+  const int np = (int)tmp.size();
+
+  // dof lists and local maps
+  for (auto& t : tmp)
+  {
+    t.dofs.reserve((size_t)t.cells.size() * N);
+    for (int32_t cell : t.cells)
+    {
+      const int32_t* dm = dofmap + (size_t)cell * N;
+      for (int k = 0; k < N; ++k)
+      {
+        if (dm[k] < 0 || dm[k] >= ndofs)
+          return fail(PMG_ERR_INVALID, "dofmap entry %d of cell %d out of range [0,%d)", dm[k], cell,
+                      ndofs);
+        t.dofs.push_back(dm[k]);
+      }
+    }
+    std::sort(t.dofs.begin(), t.dofs.end());
+    t.dofs.erase(std::unique(t.dofs.begin(), t.dofs.end()), t.dofs.end());
+    t.lmap.assign((size_t)K * N, 0);
+    for (size_t s = 0; s < t.cells.size(); ++s)
+    {
+      const int32_t* dm = dofmap + (size_t)t.cells[s] * N;
+      for (int k = 0; k < N; ++k)
+        t.lmap[s * N + k]
+            = (uint16_t)(std::lower_bound(t.dofs.begin(), t.dofs.end(), dm[k]) - t.dofs.begin());
+    }
+    plan.max_M = std::max(plan.max_M, (int)t.dofs.size());
+  }
+
+  // greedy colouring per set: a patch takes the lowest colour none of its dofs has seen
+  std::vector<int> ncolours(2, 0);
+  {
+    std::vector<uint64_t> mask(ndofs);
+    for (int set = 0; set < 2; ++set)
+    {
+      std::fill(mask.begin(), mask.end(), 0);
+      for (int p = set_first[set]; p < set_first[set + 1]; ++p)
+      {
+        uint64_t used = 0;
+        for (int32_t d : tmp[p].dofs)
+          used |= mask[d];
+        int col = 0;
+        while (col < 64 && (used >> col) & 1)
+          ++col;
+        if (col >= 64)
+          return fail(PMG_ERR_INVALID, "patch colouring needs more than 64 colours");
+        tmp[p].colour = col;
+        ncolours[set] = std::max(ncolours[set], col + 1);
+        for (int32_t d : tmp[p].dofs)
+          mask[d] |= (uint64_t)1 << col;
+      }
+    }
+  }
+  // launch index = position in stream order: lcells colours, then bcells colours
+  for (int p = 0; p < np; ++p)
+    tmp[p].launch = (p < set_first[1] ? 0 : ncolours[0]) + tmp[p].colour;
+  const int nlaunch = ncolours[0] + ncolours[1];
+  plan.n_launch_l = ncolours[0];
+  std::vector<int32_t> order(np);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int32_t a, int32_t b) { return tmp[a].launch < tmp[b].launch; });
+  plan.launch_first.assign(nlaunch, 0);
+  plan.launch_count.assign(nlaunch, 0);
+  for (int i = 0; i < np; ++i)
+    plan.launch_count[tmp[order[i]].launch]++;
+  for (int l = 1; l < nlaunch; ++l)
+    plan.launch_first[l] = plan.launch_first[l - 1] + plan.launch_count[l - 1];
+
+  // first launch that touches each dof
+  std::vector<int32_t> first(ndofs, INT32_MAX);
+  for (int p = 0; p < np; ++p)
+    for (int32_t d : tmp[p].dofs)
+      first[d] = std::min(first[d], (int32_t)tmp[p].launch);
+
+  // emit in launch order, de-duplicating the local maps
+  plan.npatch = np;
+  plan.pcell.assign((size_t)np * K, -1);
+  plan.pncell.assign(np, 0);
+  plan.poff.assign(np + 1, 0);
+  plan.lmap_id.assign(np, 0);
+  std::map<std::vector<uint16_t>, int32_t> uniq;
+  size_t total = 0;
+  for (int i = 0; i < np; ++i)
+    total += tmp[order[i]].dofs.size();
+  plan.pdofs.reserve(total);
+  for (int i = 0; i < np; ++i)
+  {
+    Tmp& t = tmp[order[i]];
+    for (size_t s = 0; s < t.cells.size(); ++s)
+      plan.pcell[(size_t)i * K + s] = t.cells[s];
+    plan.pncell[i] = (int32_t)t.cells.size();
+    for (int32_t d : t.dofs)
+    {
+      uint32_t v = (uint32_t)d;
+      if ((uint32_t)d > PD_MASK)
+        return fail(PMG_ERR_INVALID, "dof index too large for the patch encoding");
+      if (bc[d])
+        v |= PD_BC;
+      if (first[d] != t.launch)
+        v |= PD_ACC;
+      plan.pdofs.push_back(v);
+    }
+    plan.poff[i + 1] = (int32_t)plan.pdofs.size();
+    auto it = uniq.find(t.lmap);
+    if (it == uniq.end())
+    {
+      it = uniq.emplace(t.lmap, (int32_t)uniq.size()).first;
+      plan.lmaps.insert(plan.lmaps.end(), t.lmap.begin(), t.lmap.end());
+    }
+    plan.lmap_id[i] = it->second;
+  }
+  plan.nuniq = (int)uniq.size();
+  return PMG_OK;
+}
+} // namespace pmg

@@ -1,0 +1,89 @@
+// Cell patches: the scatter side of the operator without global atomics.
+//
+// The reference adds every (cell, dof) contribution to y with a global FP64
+// atomicAdd (src/laplacian.hpp:277).  On MI355X float atomics execute at the
+// memory side at a fixed request rate (MI355X_MICROARCH.md "Global float
+// atomics"); at P = 4 the 10 M atomic requests of one apply take longer than
+// streaming the whole 2 GB of operator data.  Instead, cells are grouped into
+// compact patches (2x2x2 cells at P = 4); one workgroup applies the operator to
+// a whole patch, sums the contributions of its cells in LDS, and writes each
+// patch dof once.  Patches are coloured so that no two patches of a colour share
+// a dof; colours are launched one after the other on the stream, so the write is
+// a plain store for the first patch that touches a dof and a plain
+// read-modify-write for the later ones: no atomics, no zero-fill of y, and a
+// run-to-run deterministic result.
+#pragma once
+
+#include "common.hpp"
+
+#include <cstdint>
+#include <vector>
+
+namespace pmg
+{
+constexpr uint32_t PD_BC = 0x80000000u;  // patch-dof flag: Dirichlet dof
+constexpr uint32_t PD_ACC = 0x40000000u; // patch-dof flag: an earlier launch already wrote this dof
+constexpr uint32_t PD_MASK = 0x3fffffffu;
+
+// Patch geometry per degree: a block of bx*by*bz cells on a tensor grid (long in
+// z, the direction in which a lexicographic dof numbering is contiguous, so the
+// patch's x gather / y store move long runs), processed by one workgroup in
+// `rounds` rounds of `cpr` cells.  max_m bounds the number of distinct dofs of a
+// patch (LDS size of the kernel); the builder closes a patch early rather than
+// exceed it, so any mesh and any cell order is handled.
+struct PatchShape
+{
+  int bx, by, bz; // cells per patch along x, y, z
+  int cpr;        // cells per round
+  int max_m;      // LDS capacity in dofs
+  int K() const { return bx * by * bz; }
+  int rounds() const { return (K() + cpr - 1) / cpr; }
+};
+inline constexpr PatchShape patch_shape(int P)
+{
+  switch (P)
+  {
+  case 1:
+    return {4, 4, 8, 32, 256};   // M = 5*5*9   = 225
+  case 2:
+    return {2, 2, 8, 8, 448};    // M = 5*5*17  = 425
+  case 3:
+    return {2, 2, 8, 4, 1280};   // M = 7*7*25  = 1225
+  case 4:
+    return {2, 2, 8, 4, 2688};   // M = 9*9*33  = 2673
+  case 5:
+    return {2, 2, 4, 2, 2560};   // M = 11*11*21 = 2541
+  case 6:
+    return {2, 2, 2, 1, 2240};   // M = 13^3    = 2197
+  case 7:
+    return {2, 2, 2, 1, 3392};   // M = 15^3    = 3375
+  default:
+    return {1, 1, 4, 1, 2688};   // M = 9*9*33  = 2673
+  }
+}
+
+// Host description of the patches of one operator (both cell lists).
+struct PatchPlan
+{
+  int K = 0, N = 0;
+  int npatch = 0;
+  std::vector<int32_t> pcell;   // [npatch*K] cell id per slot, -1 = empty slot (cells first)
+  std::vector<int32_t> pncell;  // [npatch] number of cells of the patch
+  std::vector<int32_t> poff;    // [npatch+1] offsets into pdofs
+  std::vector<uint32_t> pdofs;  // patch dof lists (sorted by dof), flags in the top bits
+  std::vector<int32_t> lmap_id; // [npatch] index of the patch's local map
+  std::vector<uint16_t> lmaps;  // [nuniq][K*N] position of (slot, t) in the patch dof list
+  int nuniq = 0;
+  // launches: contiguous patch ranges, in stream order; first n_launch_l belong to lcells
+  std::vector<int32_t> launch_first, launch_count;
+  int n_launch_l = 0;
+  int max_M = 0;
+};
+
+// Build the plan.  `centroid` [ncells*3] drives the grouping (tensor-grid blocks
+// when the centroids form a tensor grid, Morton-ordered chunks otherwise);
+// correctness does not depend on the grouping, only the amount of sharing does.
+int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofmap,
+                     const int8_t* bc, int32_t ndofs, const float* centroid,
+                     const int32_t* lcells, int32_t n_l, const int32_t* bcells, int32_t n_b);
+} // namespace pmg

@@ -103,9 +103,13 @@ class MatFreeLaplacian:
     def assemble_rhs(self, f: Vector, b: Vector):
         call("pmg_laplacian_assemble_rhs", self._handle, ptr(f.data), ptr(b.data), current_stream())
 
+    def launches_per_apply(self) -> int:
+        return call("pmg_laplacian_launches_per_apply", self._handle)
+
     def time_kernel(self, x: Vector, y: Vector, reps: int) -> float:
-        """Mean milliseconds of one stiffness-kernel launch over all local cells
-        (HIP events on the launch stream)."""
+        """Mean milliseconds of one stiffness-kernel launch (one patch colour);
+        an operator application issues ``launches_per_apply()`` of them (HIP
+        events on the launch stream)."""
         out = C.c_double()
         call("pmg_laplacian_time_kernel", self._handle, ptr(x.data), ptr(y.data), int(reps), C.byref(out),
              current_stream())

@@ -1,0 +1,19 @@
+"""Time the stiffness kernel alone (HIP events) for one degree / mesh size.
+usage: python tools/time_apply.py P n [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import pmg_dolfinx_amd as pm
+P, n = int(sys.argv[1]), int(sys.argv[2])
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+part = pm.BoxPartition(n); lv = part.level(P); layout = pm.make_layout(lv)
+op = pm.MatFreeLaplacian(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells, lv.bc_marker, layout)
+x = pm.Vector(layout)
+x.data.copy_(torch.randn(lv.ndofs, dtype=torch.float64, device="cuda"))
+class V: pass
+v = V(); v.data = torch.zeros(part.ncells * (P + 1) ** 3 + 16, dtype=torch.float64, device="cuda")  # room for the ABL=2 store
+op.time_kernel(x, v, 3)
+ms = op.time_kernel(x, v, reps) * op.launches_per_apply()
+N, U = (P + 1) ** 3, P ** 3
+alg = (52 * N + 8 + 17 * U) * part.ncells
+print(f"lib={os.environ.get('PMG_AMD_LIB','default')} P={P} n={n} kernel {ms*1e3:.1f} us  algorithmic {alg/ms/1e6:.0f} GB/s  ({alg/ms/1e6/8000:.3f} of 8 TB/s)")
