@@ -84,6 +84,17 @@ struct Shape
   static constexpr int RN = CPR * N;              // (cell, dof) pairs per round
   static constexpr int THREADS = ((RN + 63) / 64) * 64;
   static constexpr int ITER = (MAXM + THREADS - 1) / THREADS; // gather / store passes
+  // column kernel: a wave takes CW whole cells, a lane one (a, b) column
+  static constexpr int NQ2 = ND * ND;
+  static constexpr int CW = NQ2 <= 64 ? 64 / NQ2 : 1;
+  static constexpr int ITEMS = (K + CW - 1) / CW;  // wave-items per full patch
+#ifdef PMG_NW
+  static constexpr int NW = ITEMS < PMG_NW ? ITEMS : PMG_NW; // waves per workgroup (tuning build)
+#else
+  static constexpr int NW = ITEMS < 8 ? ITEMS : 8; // waves per workgroup
+#endif
+  static constexpr int WTHREADS = NW * 64;
+  static constexpr int WITER = (MAXM + WTHREADS - 1) / WTHREADS;
   static_assert(K % CPR == 0, "rounds must tile the patch");
   static_assert(MAXM <= 65535, "patch positions are 16-bit");
 };
@@ -124,13 +135,26 @@ __device__ inline void jacobian(const double* __restrict__ xgeom,
   detJ = J[0][0] * K[0][0] + J[0][1] * K[1][0] + J[0][2] * K[2][0];
 }
 
+// Position of (quadrature point q = (a,b,c), component pair) inside a slot's G
+// block of 3*N double2: block kernel [pair][q]; column kernel [c][pair][a*nd+b].
+__device__ __forceinline__ int gidx(int column, int nd, int N, int q, int pair)
+{
+  if (!column)
+    return pair * N + q;
+  const int nsq = nd * nd;
+  const int a = q / nsq, b = (q - a * nsq) / nd, c = q - a * nsq - b * nd;
+  return (c * 3 + pair) * nsq + a * nd + b;
+}
+
 // G for every (patch slot, q), paired layout
-__global__ void geometry_kernel(long long nslots, int nq, const int32_t* __restrict__ pcell,
+__global__ void geometry_kernel(long long nslots, int nd, int column,
+                                const int32_t* __restrict__ pcell,
                                 const double* __restrict__ xgeom,
                                 const int32_t* __restrict__ geom_dofmap,
                                 const double* __restrict__ dphi, const double* __restrict__ w,
                                 double2* __restrict__ G)
 {
+  const int nq = nd * nd * nd;
   long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= nslots * nq)
     return;
@@ -151,15 +175,17 @@ __global__ void geometry_kernel(long long nslots, int nq, const int32_t* __restr
     g5 = (K[2][0] * K[2][0] + K[2][1] * K[2][1] + K[2][2] * K[2][2]) * s;
   }
   double2* Gc = G + (size_t)slot * 3 * nq;
-  Gc[q] = make_double2(g0, g1);
-  Gc[nq + q] = make_double2(g2, g3);
-  Gc[2 * nq + q] = make_double2(g4, g5);
+  Gc[gidx(column, nd, nq, q, 0)] = make_double2(g0, g1);
+  Gc[gidx(column, nd, nq, q, 1)] = make_double2(g2, g3);
+  Gc[gidx(column, nd, nq, q, 2)] = make_double2(g4, g5);
 }
 
 // paired slot layout -> the reference's [cell][q][6]
-__global__ void geometry_export_kernel(long long nslots, int nq, const int32_t* __restrict__ pcell,
+__global__ void geometry_export_kernel(long long nslots, int nd, int column,
+                                       const int32_t* __restrict__ pcell,
                                        const double2* __restrict__ G, double* __restrict__ out)
 {
+  const int nq = nd * nd * nd;
   long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= nslots * nq)
     return;
@@ -169,7 +195,8 @@ __global__ void geometry_export_kernel(long long nslots, int nq, const int32_t* 
   if (c < 0)
     return;
   const double2* Gc = G + (size_t)slot * 3 * nq;
-  double2 a = Gc[q], b = Gc[nq + q], d = Gc[2 * nq + q];
+  double2 a = Gc[gidx(column, nd, nq, q, 0)], b = Gc[gidx(column, nd, nq, q, 1)],
+          d = Gc[gidx(column, nd, nq, q, 2)];
   double* o = out + ((size_t)c * nq + q) * 6;
   o[0] = a.x;
   o[1] = a.y;
@@ -196,7 +223,7 @@ __device__ __forceinline__ void lds_barrier()
 // ROUNDS rounds each take CPR cells through the sum-factorised operator and add
 // their contributions into the LDS accumulator; the last phase writes the patch
 // dofs back.  The G stream of round r+1 is issued at the top of round r and stays
-// in flight across the LDS-only barriers.
+// in flight across the LDS-only barriers (two rounds of operands are kept in flight).
 template <int P>
 __global__ void __launch_bounds__(Shape<P>::THREADS)
     stiffness_kernel(const double* __restrict__ x, double* __restrict__ y,
@@ -237,45 +264,55 @@ __global__ void __launch_bounds__(Shape<P>::THREADS)
 
   // ---- phase 0: every load is unconditional (clamped index) so that the compiler
   // can use counted vmcnt waits; the short loads that feed dependent loads go first.
-  uint32_t m[ITER];
-#pragma unroll
-  for (int k = 0; k < ITER; ++k)
+  int l_nxt[2];
+  double2 g01_nxt[2], g23_nxt[2], g45_nxt[2]; // operands of the next two rounds, in flight
   {
-    const int i = t + k * THREADS;
-    m[k] = pdofs[off + (i < M ? i : M - 1)];
-  }
-  const int cellk = pcell[(size_t)p * K + (t < K ? t : K - 1)];
-  const double dval = Dg[t < ND * ND ? t : ND * ND - 1];
-  double xv[ITER], yv[ITER];
+    uint32_t m[ITER];
 #pragma unroll
-  for (int k = 0; k < ITER; ++k)
-  {
-    const uint32_t dof = m[k] & PD_MASK;
-    const bool acc = (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
-    xv[k] = x[dof];
-    const double* ya = acc ? (const double*)(y + dof) : (x + dof); // re-read of x keeps it unconditional
-    yv[k] = *ya;
-  }
-  const double kapk = kappa[cellk >= 0 ? cellk : 0];
-  // round 0 operands
-  int l_nxt = lm[0];
-  double2 g01_nxt = Gp[0], g23_nxt = Gp[N], g45_nxt = Gp[2 * N]; // empty slots hold zeros
-
-#pragma unroll
-  for (int k = 0; k < ITER; ++k)
-  {
-    const int i = t + k * THREADS;
-    if (i < M)
+    for (int k = 0; k < ITER; ++k)
     {
-      const bool acc = (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
-      sx[i] = (m[k] & PD_BC) ? 0.0 : xv[k]; // Dirichlet columns masked, src/laplacian.hpp:186-189
-      sy[i] = acc ? yv[k] : 0.0;
+      const int i = t + k * THREADS;
+      m[k] = pdofs[off + (i < M ? i : M - 1)];
     }
+    const int cellk = pcell[(size_t)p * K + (t < K ? t : K - 1)];
+    const double dval = Dg[t < ND * ND ? t : ND * ND - 1];
+    double xv[ITER], yv[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+    {
+      const uint32_t dof = m[k] & PD_MASK;
+      const bool acc = (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+      xv[k] = x[dof];
+      const double* ya = acc ? (const double*)(y + dof) : (x + dof); // re-read of x keeps it unconditional
+      yv[k] = *ya;
+    }
+    const double kapk = kappa[cellk >= 0 ? cellk : 0];
+    // rounds 0 and 1 (empty slots hold zeros; the tables cover all K slots)
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+    {
+      const int rr = d < ROUNDS ? d : ROUNDS - 1;
+      l_nxt[d] = lm[rr * RN];
+      g01_nxt[d] = Gp[(size_t)rr * CPR * 3 * N];
+      g23_nxt[d] = Gp[(size_t)rr * CPR * 3 * N + N];
+      g45_nxt[d] = Gp[(size_t)rr * CPR * 3 * N + 2 * N];
+    }
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+    {
+      const int i = t + k * THREADS;
+      if (i < M)
+      {
+        const bool acc = (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+        sx[i] = (m[k] & PD_BC) ? 0.0 : xv[k]; // Dirichlet columns masked, src/laplacian.hpp:186-189
+        sy[i] = acc ? yv[k] : 0.0;
+      }
+    }
+    if (t < ND * ND)
+      sD[t] = dval;
+    if (t < K)
+      skap[t] = kapk;
   }
-  if (t < ND * ND)
-    sD[t] = dval;
-  if (t < K)
-    skap[t] = kapk;
   lds_barrier();
 
   const int a = tl / NSQ;
@@ -287,14 +324,14 @@ __global__ void __launch_bounds__(Shape<P>::THREADS)
   {
     if (r >= nrounds)
       break;
-    const int l = l_nxt;
-    const double2 g01 = g01_nxt, g23 = g23_nxt, g45 = g45_nxt;
-    if (r + 1 < ROUNDS) // compile-time after unrolling: stream the next round's operands
+    const int l = l_nxt[r & 1];
+    const double2 g01 = g01_nxt[r & 1], g23 = g23_nxt[r & 1], g45 = g45_nxt[r & 1];
+    if (r + 2 < ROUNDS) // compile-time after unrolling: stream the operands of round r + 2
     {
-      l_nxt = lm[(r + 1) * RN];
-      g01_nxt = Gp[(size_t)(r + 1) * CPR * 3 * N];
-      g23_nxt = Gp[(size_t)(r + 1) * CPR * 3 * N + N];
-      g45_nxt = Gp[(size_t)(r + 1) * CPR * 3 * N + 2 * N];
+      l_nxt[r & 1] = lm[(r + 2) * RN];
+      g01_nxt[r & 1] = Gp[(size_t)(r + 2) * CPR * 3 * N];
+      g23_nxt[r & 1] = Gp[(size_t)(r + 2) * CPR * 3 * N + N];
+      g45_nxt[r & 1] = Gp[(size_t)(r + 2) * CPR * 3 * N + 2 * N];
     }
     const bool active = inr && (r * CPR + lc < nc);
     if (active)
@@ -335,18 +372,252 @@ __global__ void __launch_bounds__(Shape<P>::THREADS)
   }
   lds_barrier();
 
-  // ---- write back: plain stores (the accumulator started from the earlier colours' y)
+  // ---- write back: plain stores (the accumulator started from the earlier colours' y);
+  // the dof list is re-read (L2) rather than kept in registers across the rounds
 #pragma unroll
   for (int k = 0; k < ITER; ++k)
   {
     const int i = t + k * THREADS;
     if (i < M)
     {
-      const uint32_t dof = m[k] & PD_MASK;
-      if (m[k] & PD_BC)
+      const uint32_t mk = pdofs[off + i];
+      const uint32_t dof = mk & PD_MASK;
+      if (mk & PD_BC)
       {
-        if (!(m[k] & PD_ACC))
-          y[dof] = xv[k]; // :273-274
+        if (!(mk & PD_ACC))
+          y[dof] = x[dof]; // :273-274
+      }
+      else
+        y[dof] = sy[i];
+    }
+  }
+}
+
+// ---- the hot kernel, column form (P <= 7) --------------------------------------
+//
+// One workgroup per patch, NW wavefronts.  Phase 0 / write-back as in the block
+// kernel.  In between every wavefront works on its own: it takes CW whole cells
+// (2 at P = 4), a lane owns the column of nd points above (a, b), keeps the
+// column's dofs and results in registers and marches through the nd layers
+// (the register-blocked 2-D scheme of libParanumal / hipBone).  Per layer the x
+// and y contractions exchange one nd x nd slice through a wave-private LDS
+// region -- LDS executes a wave's instructions in order, so no s_barrier and no
+// waitcnt is needed inside the cell loop, only a compiler fence; the z
+// contraction stays in registers with wave-uniform table entries (scalar loads).
+// A cell costs 4*nd LDS reads per point instead of 12*nd, the 1-D tables for the
+// lane's a and b sit in registers, and the layer-(k+1) slice of G is in flight
+// while layer k is computed.
+__device__ __forceinline__ void wave_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifndef PMG_WPS
+#define PMG_WPS (P <= 4 ? (2 * Shape<P>::NW + 3) / 4 : 1)
+#endif
+template <int P>
+__global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
+    stiffness_column_kernel(const double* __restrict__ x, double* __restrict__ y,
+                            const double2* __restrict__ G, const int32_t* __restrict__ poff,
+                            const uint32_t* __restrict__ pdofs,
+                            const int32_t* __restrict__ lmap_id,
+                            const uint16_t* __restrict__ lmaps, const int32_t* __restrict__ pcell,
+                            const int32_t* __restrict__ pncell, const double* __restrict__ kappa,
+                            const double* __restrict__ Dg, int first)
+{
+  using Sh = Shape<P>;
+  constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, NQ2 = Sh::NQ2, CW = Sh::CW, NW = Sh::NW;
+  constexpr int MAXM = Sh::MAXM, THREADS = Sh::WTHREADS, ITER = Sh::WITER;
+  constexpr int WL = CW * NQ2; // lanes of a wave that hold a column
+  __shared__ double sD[ND * ND];
+  __shared__ double skap[K];
+  __shared__ double sx[MAXM];
+  __shared__ double sy[MAXM];
+  __shared__ double sq[NW * WL];
+  __shared__ double sgr[NW * WL];
+  __shared__ double sgs[NW * WL];
+
+  const int p = first + blockIdx.x;
+  const int t = threadIdx.x;
+  const int off = poff[p];
+  const int M = poff[p + 1] - off; // 1 <= M <= MAXM
+  const int table = lmap_id[p];
+  const int nc = pncell[p];
+
+  // ---- phase 0: gather (unconditional loads, clamped indices: counted vmcnt waits)
+  {
+    uint32_t m[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+    {
+      const int i = t + k * THREADS;
+      m[k] = pdofs[off + (i < M ? i : M - 1)];
+    }
+    const int cellk = pcell[(size_t)p * K + (t < K ? t : K - 1)];
+    const double dval = Dg[t < ND * ND ? t : ND * ND - 1];
+    double xv[ITER], yv[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+    {
+      const uint32_t dof = m[k] & PD_MASK;
+      const bool acc = (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+      xv[k] = x[dof];
+      const double* ya = acc ? (const double*)(y + dof) : (x + dof);
+      yv[k] = *ya;
+    }
+    const double kapk = kappa[cellk >= 0 ? cellk : 0];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+    {
+      const int i = t + k * THREADS;
+      if (i < M)
+      {
+        const bool acc = (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+        sx[i] = (m[k] & PD_BC) ? 0.0 : xv[k]; // src/laplacian.hpp:186-189
+        sy[i] = acc ? yv[k] : 0.0;
+      }
+    }
+    if (t < ND * ND)
+      sD[t] = dval;
+    for (int i = t; i < K; i += THREADS)
+      skap[i] = (i == t) ? kapk : kappa[pcell[(size_t)p * K + i] >= 0 ? pcell[(size_t)p * K + i] : 0];
+  }
+  lds_barrier();
+
+  // ---- cell loop: each wave on its own
+  const int wave = t >> 6, lane = t & 63;
+  const bool lane_ok = lane < WL;
+  const int lw = lane_ok ? lane : WL - 1;
+  const int cw = lw / NQ2;          // cell of this lane inside the wave item
+  const int ab = lw - cw * NQ2;     // column: a = x index, b = y index
+  const int a = ab / ND, b = ab - a * ND;
+#ifndef PMG_GDEPTH
+#define PMG_GDEPTH 1
+#endif
+#if defined(PMG_D_IN_LDS)
+  // the lane's table rows/columns are re-read from LDS in every layer; zl is an
+  // opaque zero that keeps the compiler from hoisting the reads into 40 registers
+#define DA(m) sD[zl + a * ND + (m)]
+#define DB(m) sD[zl + b * ND + (m)]
+#define DTA(m) sD[zl + (m) * ND + a]
+#define DTB(m) sD[zl + (m) * ND + b]
+#else
+  double Da[ND], Db[ND], DTa[ND], DTb[ND]; // D[a][.], D[b][.], D[.][a], D[.][b]
+#pragma unroll
+  for (int mm = 0; mm < ND; ++mm)
+  {
+    Da[mm] = sD[a * ND + mm];
+    Db[mm] = sD[b * ND + mm];
+    DTa[mm] = sD[mm * ND + a];
+    DTb[mm] = sD[mm * ND + b];
+  }
+#define DA(m) Da[m]
+#define DB(m) Db[m]
+#define DTA(m) DTa[m]
+#define DTB(m) DTb[m]
+#endif
+  double* q_s = sq + wave * WL + cw * NQ2;  // this cell's slices
+  double* gr_s = sgr + wave * WL + cw * NQ2;
+  double* gs_s = sgs + wave * WL + cw * NQ2;
+#if defined(PMG_ABL) && PMG_ABL == 7 // timing-only ablation: gather + write-back only
+  const int items = 0;
+#else
+  const int items = (nc + CW - 1) / CW;
+#endif
+
+  for (int it = wave; it < items; it += NW)
+  {
+    const int slot = it * CW + cw;
+    const int slotc = slot < K ? slot : K - 1;
+    const uint16_t* lm = lmaps + (size_t)table * (K * N) + (size_t)slotc * N + ab;
+    const double2* Gs = G + ((size_t)p * K + slotc) * 3 * N + ab;
+    int l[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+      l[k] = lm[k * NQ2];
+    // G layers 0 .. GD-1 in flight (empty slots hold zeros)
+    constexpr int GD = ND < PMG_GDEPTH ? ND : PMG_GDEPTH;
+    double2 gq[GD][3];
+#pragma unroll
+    for (int d = 0; d < GD; ++d)
+    {
+      gq[d][0] = Gs[d * 3 * NQ2];
+      gq[d][1] = Gs[d * 3 * NQ2 + NQ2];
+      gq[d][2] = Gs[d * 3 * NQ2 + 2 * NQ2];
+    }
+    const double kap = skap[slotc];
+    double u[ND], Aq[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+    {
+      u[k] = sx[l[k]];
+      Aq[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+    {
+      const double2 g01 = gq[k % GD][0], g23 = gq[k % GD][1], g45 = gq[k % GD][2];
+      if (k + GD < ND) // refill the slot with layer k + GD
+      {
+        gq[k % GD][0] = Gs[(k + GD) * 3 * NQ2];
+        gq[k % GD][1] = Gs[(k + GD) * 3 * NQ2 + NQ2];
+        gq[k % GD][2] = Gs[(k + GD) * 3 * NQ2 + 2 * NQ2];
+      }
+#if defined(PMG_D_IN_LDS)
+      int zl = 0;
+      asm volatile("" : "+v"(zl));
+#endif
+      q_s[ab] = u[k];
+      wave_fence();
+      double qr = 0.0, qs = 0.0, qt = 0.0;
+#pragma unroll
+      for (int mm = 0; mm < ND; ++mm)
+      {
+        qr += DA(mm) * q_s[mm * ND + b];  // d/dx: sum over a, :195-199
+        qs += DB(mm) * q_s[a * ND + mm];  // d/dy: sum over b, :206-210
+        qt += Dg[k * ND + mm] * u[mm];    // d/dz: registers, uniform table, :214-218
+      }
+      const double fr = kap * (g01.x * qr + g01.y * qs + g23.x * qt); // :233
+      const double fs = kap * (g01.y * qr + g23.y * qs + g45.x * qt); // :234
+      const double ft = kap * (g23.x * qr + g45.x * qs + g45.y * qt); // :235
+      gr_s[ab] = fr;
+      gs_s[ab] = fs;
+      wave_fence();
+      double acc = 0.0;
+#pragma unroll
+      for (int mm = 0; mm < ND; ++mm)
+      {
+        acc += DTA(mm) * gr_s[mm * ND + b]; // :246-251
+        acc += DTB(mm) * gs_s[a * ND + mm]; // :255-259
+        Aq[mm] += Dg[k * ND + mm] * ft;     // :263-267
+      }
+      Aq[k] += acc;
+      wave_fence();
+    }
+    // Every lane adds (no branch: a conditional here lets the compiler sink the
+    // whole accumulation into it and keep every layer's operands live).  Empty
+    // slots have G = 0 and contribute exact zeros; idle lanes are masked to zero.
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+      atomicAdd(&sy[l[k]], lane_ok ? Aq[k] : 0.0); // :270,277 -- in LDS (ds_add_f64)
+  }
+  lds_barrier();
+
+  // ---- write back (plain stores; the accumulator started from the earlier colours' y)
+#pragma unroll
+  for (int k = 0; k < ITER; ++k)
+  {
+    const int i = t + k * THREADS;
+    if (i < M)
+    {
+      const uint32_t mk = pdofs[off + i];
+      const uint32_t dof = mk & PD_MASK;
+      if (mk & PD_BC)
+      {
+        if (!(mk & PD_ACC))
+          y[dof] = x[dof]; // :273-274
       }
       else
         y[dof] = sy[i];
@@ -355,7 +626,8 @@ __global__ void __launch_bounds__(Shape<P>::THREADS)
 }
 
 // ---- matrix-free diagonal (replaces the CSR detour of examples/pmg/main.cpp:274-279) ----
-__global__ void diagonal_kernel(long long nslots, int nd, const int32_t* __restrict__ pcell,
+__global__ void diagonal_kernel(long long nslots, int nd, int column,
+                                const int32_t* __restrict__ pcell,
                                 const double2* __restrict__ G, const int32_t* __restrict__ dofmap,
                                 const int8_t* __restrict__ bc, const double* __restrict__ kappa,
                                 const double* __restrict__ D, double* __restrict__ diag)
@@ -375,12 +647,14 @@ __global__ void diagonal_kernel(long long nslots, int nd, const int32_t* __restr
   for (int q = 0; q < nd; ++q)
   {
     double da = D[q * nd + a], db = D[q * nd + b], dc = D[q * nd + c];
-    s += da * da * Gc[q * nsq + b * nd + c].x;         // G00 at (q,b,c)
-    s += db * db * Gc[N + a * nsq + q * nd + c].y;     // G11 at (a,q,c)
-    s += dc * dc * Gc[2 * N + a * nsq + b * nd + q].y; // G22 at (a,b,q)
+    s += da * da * Gc[gidx(column, nd, N, q * nsq + b * nd + c, 0)].x; // G00 at (q,b,c)
+    s += db * db * Gc[gidx(column, nd, N, a * nsq + q * nd + c, 1)].y; // G11 at (a,q,c)
+    s += dc * dc * Gc[gidx(column, nd, N, a * nsq + b * nd + q, 2)].y; // G22 at (a,b,q)
   }
   double daa = D[a * nd + a], dbb = D[b * nd + b], dcc = D[c * nd + c];
-  s += 2.0 * (Gc[t].y * daa * dbb + Gc[N + t].x * daa * dcc + Gc[2 * N + t].x * dbb * dcc);
+  s += 2.0
+       * (Gc[gidx(column, nd, N, t, 0)].y * daa * dbb + Gc[gidx(column, nd, N, t, 1)].x * daa * dcc
+          + Gc[gidx(column, nd, N, t, 2)].x * dbb * dcc);
   int32_t dof = dofmap[(size_t)cell * N + t];
   if (!bc[dof])
     atomicAdd(&diag[dof], kappa[cell] * s);
@@ -427,9 +701,14 @@ int launch_stiffness(pmg_laplacian op, const double* x, double* y, int first, in
 {
   if (count <= 0)
     return PMG_OK;
-  stiffness_kernel<P><<<count, Shape<P>::THREADS, 0, s>>>(x, y, op->G, op->poff, op->pdofs,
-                                                          op->lmap_id, op->lmaps, op->pcell,
-                                                          op->pncell, op->kappa, op->D, first);
+  if constexpr (column_layout(P))
+    stiffness_column_kernel<P><<<count, Shape<P>::WTHREADS, 0, s>>>(
+        x, y, op->G, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell, op->pncell, op->kappa,
+        op->D, first);
+  else
+    stiffness_kernel<P><<<count, Shape<P>::THREADS, 0, s>>>(x, y, op->G, op->poff, op->pdofs,
+                                                            op->lmap_id, op->lmaps, op->pcell,
+                                                            op->pncell, op->kappa, op->D, first);
   op->launches++;
   return PMG_OK;
 }
@@ -663,8 +942,9 @@ extern "C" int pmg_laplacian_create_with_tables(
   if (nq_total > 0)
   {
     long long blocks = (nq_total + 255) / 256;
-    geometry_kernel<<<(unsigned)blocks, 256, 0, s>>>(nslots, N, op->pcell, xgeom, geom_dofmap,
-                                                    op->dphi_geom, op->gweights, op->G);
+    geometry_kernel<<<(unsigned)blocks, 256, 0, s>>>(nslots, nd, column_layout(degree) ? 1 : 0,
+                                                    op->pcell, xgeom, geom_dofmap, op->dphi_geom,
+                                                    op->gweights, op->G);
     PMG_HIP(hipGetLastError());
   }
   PMG_HIP(hipStreamSynchronize(s)); // plan's host vectors are released on return
@@ -745,9 +1025,9 @@ extern "C" int pmg_laplacian_compute_diag_inverse(pmg_laplacian op, pmg_stream s
   const long long nslots = (long long)op->npatch * op->K;
   const long long n = nslots * op->N;
   if (n > 0)
-    diagonal_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(nslots, op->nd, op->pcell, op->G,
-                                                               op->dofmap, op->bc, op->kappa,
-                                                               op->D, op->diag_inv);
+    diagonal_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
+        nslots, op->nd, column_layout(op->P) ? 1 : 0, op->pcell, op->G, op->dofmap, op->bc,
+        op->kappa, op->D, op->diag_inv);
   if (total > 0)
     diag_invert_kernel<<<(total + 255) / 256, 256, 0, s>>>(total, op->bc, op->diag_inv);
   PMG_HIP(hipGetLastError());
@@ -763,8 +1043,8 @@ extern "C" int pmg_laplacian_get_geometry(pmg_laplacian op, double* G_out, pmg_s
   const long long nslots = (long long)op->npatch * op->K;
   const long long n = nslots * op->N;
   if (n > 0)
-    geometry_export_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(nslots, op->N, op->pcell,
-                                                                      op->G, G_out);
+    geometry_export_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
+        nslots, op->nd, column_layout(op->P) ? 1 : 0, op->pcell, op->G, G_out);
   PMG_HIP(hipGetLastError());
   return PMG_OK;
 }

@@ -62,6 +62,20 @@ inline constexpr PatchShape patch_shape(int P)
   }
 }
 
+// Two kernel families consume the patches.  "column" (P <= 7): one wavefront
+// takes whole cells, a lane owns the column of nd points above (a, b) -- the
+// per-cell tables are then stored layer by layer, index c*nd^2 + a*nd + b.
+// "block" (P = 8, 81 columns do not fit a 64-lane wave): one thread per
+// (cell, dof), tables in the dofmap order t = a*nd^2 + b*nd + c.
+inline constexpr bool column_layout(int P) { return P <= 7; }
+inline int table_index(bool column, int nd, int t)
+{
+  if (!column)
+    return t;
+  const int a = t / (nd * nd), b = (t / nd) % nd, c = t % nd;
+  return c * nd * nd + a * nd + b;
+}
+
 // Host description of the patches of one operator (both cell lists).
 struct PatchPlan
 {

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Timing-only ablation builds of the library (results are WRONG by construction;
-# never used by tests or bench).  PMG_ABL=4: memory skeleton of the stiffness
-# kernel (all loads/stores, no contraction).  Output: tools/abl/libpmg_amd_abl<k>.so
+# Tuning / timing-only variant builds of the library into tools/abl/ (never used
+# by tests or bench).  Usage: tools/build_ablation.sh NAME "-DFLAG ..." [NAME FLAGS ...]
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/abl
-for k in 4 5 6; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -DPMG_ABL=$k \
-    -o tools/abl/libpmg_amd_abl$k.so pmg-dolfinx_amd/csrc/*.hip
+while [ $# -ge 2 ]; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics $2 \
+    -o tools/abl/libpmg_amd_$1.so pmg-dolfinx_amd/csrc/*.hip
+  shift 2
 done
