@@ -597,11 +597,13 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
       wave_fence();
     }
     // Every lane adds (no branch: a conditional here lets the compiler sink the
-    // whole accumulation into it and keep every layer's operands live).  Empty
-    // slots have G = 0 and contribute exact zeros; idle lanes are masked to zero.
+    // whole accumulation into it and keep every layer's operands live); lanes
+    // without a cell (idle lanes, slots past the patch's cells -- their indices
+    // were clamped onto a real slot) add an exact zero.
+    const bool contributes = lane_ok && slot < nc;
 #pragma unroll
     for (int k = 0; k < ND; ++k)
-      atomicAdd(&sy[l[k]], lane_ok ? Aq[k] : 0.0); // :270,277 -- in LDS (ds_add_f64)
+      atomicAdd(&sy[l[k]], contributes ? Aq[k] : 0.0); // :270,277 -- in LDS (ds_add_f64)
   }
   lds_barrier();
 

@@ -66,6 +66,22 @@ def test_apply_parity_all_degrees(pm, P):
     assert _relerr(d.data_copy(), A.diag_inverse()) < 1e-12
 
 
+@pytest.mark.parametrize("P,n", [(1, (8, 8, 16)), (2, (4, 4, 16)), (3, (4, 4, 8)), (4, (4, 4, 8)), (5, (4, 4, 4)),
+                                 (6, (2, 4, 4)), (7, (2, 2, 4)), (8, (2, 2, 8))])
+def test_apply_parity_full_patches(pm, P, n):
+    """Meshes large enough that every patch of the operator is full (at P = 2 a
+    wavefront takes 7 cells, which does not divide the 32 cells of a patch), on a
+    tensor grid so that the patch builder takes its structured path."""
+    part, lv, layout, op, A = _single_level(pm, n, P, warped=False)
+    u = np.random.default_rng(100 + P).standard_normal(lv.ndofs)
+    x, y = _vec(pm, layout, u), pm.Vector(layout)
+    y.set(-3.0)
+    op(x, y)
+    assert _relerr(y.data_copy(), A.apply(u)) < 1e-12
+    op(x, y)  # second application: no dependence on the previous content of y
+    assert _relerr(y.data_copy(), A.apply(u)) < 1e-12
+
+
 def test_config1_seven_point_stencil(pm):
     """BASELINE config 1: 16^3 hexes, P=1 == 7-point finite differences."""
     part, lv, layout, op, A = _single_level(pm, 16, 1, warped=False)
