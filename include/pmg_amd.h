@@ -78,8 +78,9 @@ int pmg_tqli(double* d, double* e, int n);
  * (start moving send_buffer -> the neighbours' recv_buffer, asynchronously with
  * respect to `stream`), and with phase 1 before the unpack kernel is enqueued
  * (make `stream` wait for the arrival).  Phases 2 / 3 are the same for the
- * reverse scatter (recv_buffer -> the owners' send_buffer).  It must return 0.  With no neighbours
- * (n_send == n_recv == 0) it is never called and may be NULL.
+ * reverse scatter (recv_buffer -> the owners' send_buffer).  It must return 0.  If `exchange`
+ * is non-NULL it is called on every scatter, also when n_send == n_recv == 0 (the
+ * caller's exchange is typically a collective); pass NULL on a single rank.
  *
  * `allreduce_sum` sums `n` host doubles over all ranks in place (the
  * reference's MPI_Allreduce, src/vector.hpp:350); NULL on a single rank. */

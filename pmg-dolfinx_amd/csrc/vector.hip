@@ -448,6 +448,8 @@ extern "C" int pmg_layout_create(pmg_layout* out, int32_t size_local, int32_t nu
               "pmg_layout_create: recv arrays missing");
   PMG_REQUIRE((n_send == 0 && n_recv == 0) || exchange,
               "pmg_layout_create: neighbours given but no exchange callback");
+  // with a callback every scatter calls it (it is a collective on the caller's
+  // side), even when this rank shares no dof with anybody
   auto* l = new pmg_layout_s;
   l->size_local = size_local;
   l->num_ghosts = num_ghosts;
@@ -489,8 +491,8 @@ extern "C" int32_t pmg_layout_num_ghosts(pmg_layout l) { return l ? l->num_ghost
 extern "C" int pmg_scatter_fwd_begin(pmg_layout l, const double* x, pmg_stream stream)
 {
   PMG_REQUIRE(l && x, "pmg_scatter_fwd_begin: NULL argument");
-  if (l->n_send == 0 && l->n_recv == 0)
-    return PMG_OK;
+  if (!l->exchange)
+    return PMG_OK; // single rank
   if (l->n_send > 0)
     pack_kernel<<<ew_blocks(l->n_send), EW_THREADS, 0, S(stream)>>>(l->n_send, l->send_idx, x,
                                                                     l->send_buf);
@@ -504,8 +506,8 @@ extern "C" int pmg_scatter_fwd_begin(pmg_layout l, const double* x, pmg_stream s
 extern "C" int pmg_scatter_fwd_end(pmg_layout l, double* x, pmg_stream stream)
 {
   PMG_REQUIRE(l && x, "pmg_scatter_fwd_end: NULL argument");
-  if (l->n_send == 0 && l->n_recv == 0)
-    return PMG_OK;
+  if (!l->exchange)
+    return PMG_OK; // single rank
   if (l->exchange(l->user, 1, stream) != 0)
     return fail(PMG_ERR_INVALID, "exchange callback (end) failed");
   if (l->n_recv > 0)
@@ -520,8 +522,8 @@ extern "C" int pmg_scatter_fwd_end(pmg_layout l, double* x, pmg_stream stream)
 extern "C" int pmg_scatter_rev_begin(pmg_layout l, const double* x, pmg_stream stream)
 {
   PMG_REQUIRE(l && x, "pmg_scatter_rev_begin: NULL argument");
-  if (l->n_send == 0 && l->n_recv == 0)
-    return PMG_OK;
+  if (!l->exchange)
+    return PMG_OK; // single rank
   if (l->n_recv > 0)
     pack_kernel<<<ew_blocks(l->n_recv), EW_THREADS, 0, S(stream)>>>(
         l->n_recv, l->recv_idx, x + l->size_local, l->recv_buf);
@@ -535,8 +537,8 @@ extern "C" int pmg_scatter_rev_begin(pmg_layout l, const double* x, pmg_stream s
 extern "C" int pmg_scatter_rev_end(pmg_layout l, double* x, pmg_stream stream)
 {
   PMG_REQUIRE(l && x, "pmg_scatter_rev_end: NULL argument");
-  if (l->n_send == 0 && l->n_recv == 0)
-    return PMG_OK;
+  if (!l->exchange)
+    return PMG_OK; // single rank
   if (l->exchange(l->user, 3, stream) != 0)
     return fail(PMG_ERR_INVALID, "exchange callback (rev end) failed");
   if (l->n_send > 0)

@@ -71,6 +71,10 @@ class Layout:
         self.recv_buffer = torch.zeros(max(n_recv, 1), dtype=torch.float64, device=self.device)
         dist = _dist()
         self._world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # every rank of a multi-rank group takes part in every exchange (a collective),
+        # even one that happens to share no dof with anybody
+        self.distributed = self._world > 1
+        self._staged = self.distributed and dist.get_backend(group) != "nccl"
         self._splits()
         # callbacks must outlive the handle
         self._cb_exchange = _lib.EXCHANGE_FN(self._exchange) if self.distributed else _lib.EXCHANGE_FN()
@@ -98,6 +102,8 @@ class Layout:
     def _exchange(self, user, phase, stream):
         try:
             dist = _dist()
+            if self._staged:
+                return self._exchange_staged(phase)
             if phase == 0:  # forward begin: owners' packed values -> ghosts
                 self._work = dist.all_to_all_single(
                     self.recv_buffer[: self.n_recv], self.send_buffer[: self.n_send], self._recv_splits,
@@ -117,6 +123,25 @@ class Layout:
 
             traceback.print_exc(file=sys.stderr)
             return 1
+
+    def _exchange_staged(self, phase):
+        """Exchange through host memory for process groups that cannot move device
+        buffers (gloo): blocking, no overlap.  Used to run the distributed path on
+        machines without RCCL-capable peers (e.g. two ranks sharing one GPU in the
+        test-suite); the RCCL path above is the production one."""
+        import torch
+
+        dist = _dist()
+        if phase in (0, 2):
+            fwd = phase == 0
+            src = self.send_buffer[: self.n_send] if fwd else self.recv_buffer[: self.n_recv]
+            dst = self.recv_buffer[: self.n_recv] if fwd else self.send_buffer[: self.n_send]
+            insp, outsp = (self._send_splits, self._recv_splits) if fwd else (self._recv_splits, self._send_splits)
+            host_in = src.cpu()  # synchronises with the pack kernel on the current stream
+            host_out = torch.empty(dst.numel(), dtype=torch.float64)
+            dist.all_to_all_single(host_out, host_in, outsp, insp, group=self.group)
+            dst.copy_(host_out)
+        return 0
 
     def _allreduce(self, user, values, n):
         try:
