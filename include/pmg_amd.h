@@ -223,10 +223,25 @@ int pmg_interpolator_create(pmg_interpolator* out, pmg_layout layout_coarse,
                             int32_t ncells, const int32_t* dofmap_coarse,
                             const int32_t* dofmap_fine, const int32_t* lcells, int32_t n_lcells,
                             const int32_t* bcells, int32_t n_bcells, pmg_stream stream);
+/* Same, sharing the cell patches (grouping, colours, launch order) of the
+ * fine-level operator: both transfers then run one workgroup per patch with LDS
+ * accumulation -- no global atomics, no zero-fill -- and the prolongation can be
+ * fused with the correction.  fine_operator may be NULL (== pmg_interpolator_create). */
+int pmg_interpolator_create_with_operator(pmg_interpolator* out, pmg_layout layout_coarse,
+                                          pmg_layout layout_fine, int degree_coarse,
+                                          int degree_fine, int32_t ncells,
+                                          const int32_t* dofmap_coarse, const int32_t* dofmap_fine,
+                                          const int32_t* lcells, int32_t n_lcells,
+                                          const int32_t* bcells, int32_t n_bcells,
+                                          pmg_laplacian fine_operator, pmg_stream stream);
 int pmg_interpolator_destroy(pmg_interpolator ip);
 /* interpolate(Q1_vector, Q2_vector), :186-239: prolongation, updates the ghosts of `coarse`. */
 int pmg_interpolator_interpolate(pmg_interpolator ip, double* coarse, double* fine,
                                  pmg_stream stream);
+/* fine += P coarse in one pass: interpolate + the axpy of src/pmg.hpp:123-129
+ * (only for interpolators created with an operator). */
+int pmg_interpolator_interpolate_add(pmg_interpolator ip, double* coarse, double* fine,
+                                     pmg_stream stream);
 /* reverse_interpolate(Q2_vector, Q1_vector), :246-303: restriction (multiplicity-
  * weighted transpose), updates the ghosts of `fine`, zeroes `coarse` first. */
 int pmg_interpolator_reverse_interpolate(pmg_interpolator ip, double* fine, double* coarse,

@@ -88,6 +88,11 @@ _SIGS = {
         C.c_int,
         [C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int32, vp, vp, c_ip, C.c_int32, c_ip, C.c_int32, vp],
     ),
+    "pmg_interpolator_create_with_operator": (
+        C.c_int,
+        [C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int32, vp, vp, c_ip, C.c_int32, c_ip, C.c_int32, vp, vp],
+    ),
+    "pmg_interpolator_interpolate_add": (C.c_int, [vp, vp, vp, vp]),
     "pmg_interpolator_destroy": (C.c_int, [vp]),
     "pmg_interpolator_interpolate": (C.c_int, [vp, vp, vp, vp]),
     "pmg_interpolator_reverse_interpolate": (C.c_int, [vp, vp, vp, vp]),

@@ -6,8 +6,18 @@
 // applied as the tensor product of the 1-D table M1 (nd_f x nd_c) it is built
 // from (entries with |v| <= 1e-12 dropped, :119-135).
 #include "common.hpp"
+#include "patches.hpp"
+
+#include <algorithm>
+#include <map>
 
 using namespace pmg;
+
+namespace pmg
+{
+PatchView laplacian_patches(pmg_laplacian op);
+pmg_layout laplacian_layout(pmg_laplacian op);
+}
 
 struct pmg_interpolator_s
 {
@@ -22,6 +32,18 @@ struct pmg_interpolator_s
   int32_t* bcells = nullptr;
   int32_t n_l = 0, n_b = 0;
   int cpb = 1, threads = 64;
+  // ---- patch path: shares the cell patches (grouping, colours, launch order,
+  // fine dof lists and local maps) of the fine-level operator
+  bool patched = false;
+  PatchView fv;
+  int32_t* cpoff = nullptr;    // [npatch+1] coarse dof lists of the same patches
+  uint32_t* cpdofs = nullptr;  // sorted coarse dofs, PD_ACC = an earlier launch wrote it
+  int32_t* clmap_id = nullptr; // [npatch]
+  uint16_t* clmaps = nullptr;  // [table][K*Nc] position of (slot, coarse local dof)
+  uint8_t* pmult = nullptr;    // [fine pdofs entries] multiplicity of the fine dof (:172-178)
+  int cmax_m = 0;
+  int pwaves = 4;
+  size_t pshm = 0;
 };
 
 namespace
@@ -129,6 +151,261 @@ __global__ void restrict_kernel(int ncells_list, const int32_t* __restrict__ cel
   atomicAdd(&coarse[dmc[(size_t)cell * Nc + tl]], v); // src/interpolate.hpp:84
 }
 
+// ---------------------------------------------------------------------------
+// Patch form of the two transfers.  One workgroup per patch of the fine-level
+// operator; each wavefront takes whole cells and applies the cell matrix as three
+// 1-D contractions through a wave-private LDS scratch (nothing but a compiler fence
+// between the stages: LDS executes a wave's instructions in order).
+//   prolongation: every patch dof is written once, by the patch that touches it
+//     first in launch order -- so the correction u += P u_c needs no temporary and
+//     all patches run in one launch;
+//   restriction: contributions are summed in LDS; a patch adds its sums to the coarse
+//     vector with one atomic per patch coarse dof (long runs: a few dozen 64-byte
+//     requests per patch; the reference issues one FP64 atomicAdd per (cell, coarse
+//     dof), src/interpolate.hpp:84).  A coloured write-back like the operator's is
+//     available in the kernel (atomic_out = 0).
+__device__ __forceinline__ void tfence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void tbarrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ int ftab(int column, int ndf, int a, int b, int c)
+{
+  return column ? c * ndf * ndf + a * ndf + b : (a * ndf + b) * ndf + c;
+}
+
+struct TransferArgs
+{
+  int first, ndc, ndf, column, K, max_mf, max_mc;
+  const int32_t *poff, *lmap_id, *pncell, *cpoff, *clmap_id;
+  const uint32_t *pdofs, *cpdofs;
+  const uint16_t *lmaps, *clmaps;
+  const uint8_t* pmult;
+  const double* M1;
+};
+
+template <int NDC, int NDF>
+__global__ void prolong_patch_kernel(TransferArgs A, const double* __restrict__ coarse,
+                                     double* __restrict__ fine, int add)
+{
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int ndc = NDC, ndf = NDF, Nc = ndc * ndc * ndc, Nf = ndf * ndf * ndf;
+  constexpr int n1 = ndf * ndc * ndc, n2 = ndf * ndf * ndc;
+  double* sM = smem;                  // [ndf*ndc]
+  double* sc = sM + ndf * ndc;        // [max_mc] coarse values of the patch
+  double* sf = sc + A.max_mc;         // [max_mf] fine values of the patch
+  double* scratch = sf + A.max_mf;    // per wave: uc[Nc] t1[n1] t2[n2]
+  const int p = A.first + blockIdx.x, t = threadIdx.x;
+  const int off = A.poff[p], Mf = A.poff[p + 1] - off;
+  const int coff = A.cpoff[p], Mc = A.cpoff[p + 1] - coff;
+  const int nc = A.pncell[p];
+  for (int i = t; i < ndf * ndc; i += blockDim.x)
+    sM[i] = A.M1[i];
+  for (int i = t; i < Mc; i += blockDim.x)
+    sc[i] = coarse[A.cpdofs[coff + i] & PD_MASK];
+  tbarrier();
+  const int wave = t >> 6, lane = t & 63, nw = blockDim.x >> 6;
+  double* uc = scratch + (size_t)wave * (Nc + n1 + n2);
+  double* t1 = uc + Nc;
+  double* t2 = t1 + n1;
+  const uint16_t* cl = A.clmaps + (size_t)A.clmap_id[p] * A.K * Nc;
+  const uint16_t* fl = A.lmaps + (size_t)A.lmap_id[p] * A.K * Nf;
+  for (int slot = wave; slot < nc; slot += nw)
+  {
+    for (int o = lane; o < Nc; o += 64)
+      uc[o] = sc[cl[(size_t)slot * Nc + o]];
+    tfence();
+    for (int o = lane; o < n1; o += 64) // (a, j, k): sum over i
+    {
+      const int a = o / (ndc * ndc), jk = o - a * ndc * ndc;
+      double v = 0.0;
+      #pragma unroll
+      for (int i = 0; i < ndc; ++i)
+        v += sM[a * ndc + i] * uc[i * ndc * ndc + jk];
+      t1[o] = v;
+    }
+    tfence();
+    for (int o = lane; o < n2; o += 64) // (a, b, k): sum over j
+    {
+      const int a = o / (ndf * ndc), r = o - a * ndf * ndc, b = r / ndc, k = r - b * ndc;
+      double v = 0.0;
+      #pragma unroll
+      for (int j = 0; j < ndc; ++j)
+        v += sM[b * ndc + j] * t1[(a * ndc + j) * ndc + k];
+      t2[o] = v;
+    }
+    tfence();
+    for (int o = lane; o < Nf; o += 64) // (a, b, c): sum over k
+    {
+      const int a = o / (ndf * ndf), r = o - a * ndf * ndf, b = r / ndf, c = r - b * ndf;
+      double v = 0.0;
+      #pragma unroll
+      for (int k = 0; k < ndc; ++k)
+        v += sM[c * ndc + k] * t2[(a * ndf + b) * ndc + k];
+      sf[fl[(size_t)slot * Nf + ftab(A.column, ndf, a, b, c)]] = v; // shared dofs: identical values
+    }
+    tfence();
+  }
+  tbarrier();
+  for (int i = t; i < Mf; i += blockDim.x)
+  {
+    const uint32_t m = A.pdofs[off + i];
+    if (!(m & PD_ACC)) // this patch is the first (only) writer of the dof
+    {
+      const uint32_t d = m & PD_MASK;
+      fine[d] = add ? fine[d] + sf[i] : sf[i]; // src/interpolate.hpp:42 (+ src/pmg.hpp:129 when add)
+    }
+  }
+}
+
+template <int NDC, int NDF>
+__global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__ fine,
+                                      double* __restrict__ coarse, int atomic_out)
+{
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int ndc = NDC, ndf = NDF, Nc = ndc * ndc * ndc, Nf = ndf * ndf * ndf;
+  constexpr int n1 = ndf * ndc * ndc, n2 = ndf * ndf * ndc;
+  double* sM = smem;
+  double* sc = sM + ndf * ndc;     // [max_mc] coarse accumulators
+  double* sf = sc + A.max_mc;      // [max_mf] weighted fine values
+  double* scratch = sf + A.max_mf; // per wave: w[Nf] t2[n2] t1[n1]
+  const int p = A.first + blockIdx.x, t = threadIdx.x;
+  const int off = A.poff[p], Mf = A.poff[p + 1] - off;
+  const int coff = A.cpoff[p], Mc = A.cpoff[p + 1] - coff;
+  const int nc = A.pncell[p];
+  for (int i = t; i < ndf * ndc; i += blockDim.x)
+    sM[i] = A.M1[i];
+  for (int i = t; i < Mf; i += blockDim.x)
+    sf[i] = fine[A.pdofs[off + i] & PD_MASK] / (double)A.pmult[off + i]; // src/interpolate.hpp:81-82
+  for (int i = t; i < Mc; i += blockDim.x)
+  {
+    const uint32_t m = A.cpdofs[coff + i];
+    sc[i] = (!atomic_out && (m & PD_ACC)) ? coarse[m & PD_MASK] : 0.0; // onto the earlier colours
+  }
+  tbarrier();
+  const int wave = t >> 6, lane = t & 63, nw = blockDim.x >> 6;
+  double* w = scratch + (size_t)wave * (Nf + n1 + n2);
+  double* t2 = w + Nf;
+  double* t1 = t2 + n2;
+  const uint16_t* cl = A.clmaps + (size_t)A.clmap_id[p] * A.K * Nc;
+  const uint16_t* fl = A.lmaps + (size_t)A.lmap_id[p] * A.K * Nf;
+  for (int slot = wave; slot < nc; slot += nw)
+  {
+    for (int o = lane; o < Nf; o += 64)
+    {
+      const int a = o / (ndf * ndf), r = o - a * ndf * ndf, b = r / ndf, c = r - b * ndf;
+      w[o] = sf[fl[(size_t)slot * Nf + ftab(A.column, ndf, a, b, c)]];
+    }
+    tfence();
+    for (int o = lane; o < n2; o += 64) // (a, b, k): sum over c
+    {
+      const int ab = o / ndc, k = o - ab * ndc;
+      double v = 0.0;
+      #pragma unroll
+      for (int c = 0; c < ndf; ++c)
+        v += sM[c * ndc + k] * w[ab * ndf + c];
+      t2[o] = v;
+    }
+    tfence();
+    for (int o = lane; o < n1; o += 64) // (a, j, k): sum over b
+    {
+      const int a = o / (ndc * ndc), r = o - a * ndc * ndc, j = r / ndc, k = r - j * ndc;
+      double v = 0.0;
+      #pragma unroll
+      for (int b = 0; b < ndf; ++b)
+        v += sM[b * ndc + j] * t2[(a * ndf + b) * ndc + k];
+      t1[o] = v;
+    }
+    tfence();
+    for (int o = lane; o < Nc; o += 64) // (i, j, k): sum over a
+    {
+      const int i = o / (ndc * ndc), jk = o - i * ndc * ndc;
+      double v = 0.0;
+      #pragma unroll
+      for (int a = 0; a < ndf; ++a)
+        v += sM[a * ndc + i] * t1[a * ndc * ndc + jk];
+      atomicAdd(&sc[cl[(size_t)slot * Nc + o]], v); // in LDS
+    }
+    tfence();
+  }
+  tbarrier();
+  if (atomic_out) // single launch over all patches, coarse zero-filled beforehand
+  {
+    for (int i = t; i < Mc; i += blockDim.x)
+      atomicAdd(&coarse[A.cpdofs[coff + i] & PD_MASK], sc[i]);
+  }
+  else
+    for (int i = t; i < Mc; i += blockDim.x)
+      coarse[A.cpdofs[coff + i] & PD_MASK] = sc[i];
+}
+
+// (coarse nd, fine nd) -> kernel instantiation
+#define PMG_FOR_PAIRS(X)                                                                            \
+  X(2, 3) X(2, 4) X(2, 5) X(2, 6) X(2, 7) X(2, 8) X(2, 9) X(3, 4) X(3, 5) X(3, 6) X(3, 7) X(3, 8)   \
+  X(3, 9) X(4, 5) X(4, 6) X(4, 7) X(4, 8) X(4, 9) X(5, 6) X(5, 7) X(5, 8) X(5, 9) X(6, 7) X(6, 8)   \
+  X(6, 9) X(7, 8) X(7, 9) X(8, 9)
+
+int launch_prolong_patch(int ndc, int ndf, int grid, int threads, size_t shm, hipStream_t s,
+                         const TransferArgs& A, const double* coarse, double* fine, int add)
+{
+#define X(C, F)                                                                                    \
+  if (ndc == C && ndf == F)                                                                        \
+  {                                                                                                \
+    prolong_patch_kernel<C, F><<<grid, threads, shm, s>>>(A, coarse, fine, add);                   \
+    return PMG_OK;                                                                                 \
+  }
+  PMG_FOR_PAIRS(X)
+#undef X
+  return fail(PMG_ERR_INVALID, "unsupported degree pair");
+}
+
+int launch_restrict_patch(int ndc, int ndf, int grid, int threads, size_t shm, hipStream_t s,
+                          const TransferArgs& A, const double* fine, double* coarse, int atomic_out)
+{
+#define X(C, F)                                                                                    \
+  if (ndc == C && ndf == F)                                                                        \
+  {                                                                                                \
+    restrict_patch_kernel<C, F><<<grid, threads, shm, s>>>(A, fine, coarse, atomic_out);           \
+    return PMG_OK;                                                                                 \
+  }
+  PMG_FOR_PAIRS(X)
+#undef X
+  return fail(PMG_ERR_INVALID, "unsupported degree pair");
+}
+
+int set_patch_kernel_lds(int ndc, int ndf, int bytes)
+{
+#define X(C, F)                                                                                    \
+  if (ndc == C && ndf == F)                                                                        \
+  {                                                                                                \
+    PMG_HIP(hipFuncSetAttribute((const void*)prolong_patch_kernel<C, F>,                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));               \
+    PMG_HIP(hipFuncSetAttribute((const void*)restrict_patch_kernel<C, F>,                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes));               \
+    return PMG_OK;                                                                                 \
+  }
+  PMG_FOR_PAIRS(X)
+#undef X
+  return fail(PMG_ERR_INVALID, "unsupported degree pair");
+}
+
+// multiplicity of every fine patch dof, as a byte next to pdofs
+__global__ void patch_mult_kernel(long long n, const uint32_t* __restrict__ pdofs,
+                                  const double* __restrict__ inv_mult, uint8_t* __restrict__ pm)
+{
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+  {
+    const double im = inv_mult[pdofs[i] & PD_MASK];
+    pm[i] = (uint8_t)(im > 0.0 ? 1.0 / im + 0.5 : 1.0);
+  }
+}
+
 template <typename T>
 int upload(T** dst, const T* src, size_t n, hipStream_t s)
 {
@@ -139,10 +416,91 @@ int upload(T** dst, const T* src, size_t n, hipStream_t s)
 }
 } // namespace
 
+namespace
+{
+TransferArgs make_args(pmg_interpolator ip, int first)
+{
+  TransferArgs A;
+  A.first = first;
+  A.ndc = ip->ndc;
+  A.ndf = ip->ndf;
+  A.column = ip->fv.column ? 1 : 0;
+  A.K = ip->fv.K;
+  A.max_mf = ip->fv.max_m;
+  A.max_mc = ip->cmax_m;
+  A.poff = ip->fv.poff;
+  A.lmap_id = ip->fv.lmap_id;
+  A.pncell = ip->fv.pncell;
+  A.cpoff = ip->cpoff;
+  A.clmap_id = ip->clmap_id;
+  A.pdofs = ip->fv.pdofs;
+  A.cpdofs = ip->cpdofs;
+  A.lmaps = ip->fv.lmaps;
+  A.clmaps = ip->clmaps;
+  A.pmult = ip->pmult;
+  A.M1 = ip->M1;
+  return A;
+}
+
+// patches of the interior cell list come first in launch order
+int interior_patches(pmg_interpolator ip)
+{
+  const auto& lf = *ip->fv.launch_first;
+  return ip->fv.n_launch_l < (int)lf.size() ? lf[ip->fv.n_launch_l] : ip->fv.npatch;
+}
+
+int prolong_patched(pmg_interpolator ip, double* coarse, double* fine, int add, hipStream_t s)
+{
+  const int n_int = interior_patches(ip), n_all = ip->fv.npatch;
+  PMG_TRY(pmg_scatter_fwd_begin(ip->lc, coarse, (pmg_stream)s)); // src/interpolate.hpp:202
+  if (n_int > 0)
+    PMG_TRY(launch_prolong_patch(ip->ndc, ip->ndf, n_int, ip->pwaves * 64, ip->pshm, s, make_args(ip, 0),
+                                 coarse, fine, add));
+  PMG_TRY(pmg_scatter_fwd_end(ip->lc, coarse, (pmg_stream)s)); // :217
+  if (n_all > n_int)
+    PMG_TRY(launch_prolong_patch(ip->ndc, ip->ndf, n_all - n_int, ip->pwaves * 64, ip->pshm, s,
+                                 make_args(ip, n_int), coarse, fine, add));
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+int restrict_patched(pmg_interpolator ip, double* fine, double* coarse, hipStream_t s)
+{
+  // One launch per cell list; the patch sums go to the (small) coarse vector with
+  // FP64 atomics: a patch issues a few dozen 64-byte atomic requests (its coarse
+  // dofs form long runs), three orders of magnitude fewer than one per
+  // (cell, coarse dof) as in src/interpolate.hpp:84, and 8 colour launches of a
+  // ~30 us kernel would cost more than they save.
+  const int n_int = interior_patches(ip), n_all = ip->fv.npatch;
+  PMG_TRY(pmg_scatter_fwd_begin(ip->lf, fine, (pmg_stream)s));             // :264
+  PMG_HIP(hipMemsetAsync(coarse, 0, sizeof(double) * ip->lc->total(), s)); // :270
+  if (n_int > 0)
+    PMG_TRY(launch_restrict_patch(ip->ndc, ip->ndf, n_int, ip->pwaves * 64, ip->pshm, s,
+                                  make_args(ip, 0), fine, coarse, 1));
+  PMG_TRY(pmg_scatter_fwd_end(ip->lf, fine, (pmg_stream)s)); // :281
+  if (n_all > n_int)
+    PMG_TRY(launch_restrict_patch(ip->ndc, ip->ndf, n_all - n_int, ip->pwaves * 64, ip->pshm, s,
+                                  make_args(ip, n_int), fine, coarse, 1));
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+} // namespace
+
 namespace pmg
 {
+bool interp_is_patched(pmg_interpolator ip) { return ip->patched; }
+
+// fine += P coarse in one pass (src/pmg.hpp:123-129 fused); patch path only
+int interp_prolong_add(pmg_interpolator ip, double* coarse, double* fine, hipStream_t s)
+{
+  PMG_REQUIRE(ip->patched, "interp_prolong_add needs the patch path");
+  return prolong_patched(ip, coarse, fine, 1, s);
+}
+
 int interp_prolong(pmg_interpolator ip, double* coarse, double* fine, hipStream_t s)
 {
+  if (ip->patched)
+    return prolong_patched(ip, coarse, fine, 0, s);
   const size_t shm = sizeof(double) * (ip->ndf * ip->ndc + (size_t)ip->cpb * ip->Nc);
   PMG_TRY(pmg_scatter_fwd_begin(ip->lc, coarse, (pmg_stream)s)); // src/interpolate.hpp:202
   if (ip->n_l > 0)
@@ -158,6 +516,8 @@ int interp_prolong(pmg_interpolator ip, double* coarse, double* fine, hipStream_
 
 int interp_restrict(pmg_interpolator ip, double* fine, double* coarse, hipStream_t s)
 {
+  if (ip->patched)
+    return restrict_patched(ip, fine, coarse, s);
   const size_t shm = sizeof(double) * (ip->ndf * ip->ndc + (size_t)ip->cpb * ip->Nf);
   PMG_TRY(pmg_scatter_fwd_begin(ip->lf, fine, (pmg_stream)s));             // :264
   PMG_HIP(hipMemsetAsync(coarse, 0, sizeof(double) * ip->lc->total(), s)); // :270
@@ -246,10 +606,140 @@ extern "C" int pmg_interpolator_create(pmg_interpolator* out, pmg_layout layout_
   return PMG_OK;
 }
 
+extern "C" int pmg_interpolator_create_with_operator(
+    pmg_interpolator* out, pmg_layout layout_coarse, pmg_layout layout_fine, int degree_coarse,
+    int degree_fine, int32_t ncells, const int32_t* dofmap_coarse, const int32_t* dofmap_fine,
+    const int32_t* lcells, int32_t n_lcells, const int32_t* bcells, int32_t n_bcells,
+    pmg_laplacian fine_operator, pmg_stream stream)
+{
+  PMG_TRY(pmg_interpolator_create(out, layout_coarse, layout_fine, degree_coarse, degree_fine, ncells,
+                                  dofmap_coarse, dofmap_fine, lcells, n_lcells, bcells, n_bcells,
+                                  stream));
+  if (!fine_operator)
+    return PMG_OK;
+  pmg_interpolator ip = *out;
+  hipStream_t s = S(stream);
+  PMG_REQUIRE(laplacian_layout(fine_operator) == layout_fine,
+              "pmg_interpolator_create_with_operator: operator is not on the fine layout");
+  ip->fv = laplacian_patches(fine_operator);
+  PMG_REQUIRE(ip->fv.P == degree_fine,
+              "pmg_interpolator_create_with_operator: operator degree %d != fine degree %d",
+              ip->fv.P, degree_fine);
+  const PatchView& v = ip->fv;
+  const int K = v.K, Nc = ip->Nc, np = v.npatch;
+  const int nc_total = layout_coarse->total();
+
+  std::vector<int32_t> h_dmc((size_t)ncells * Nc);
+  PMG_HIP(hipMemcpyAsync(h_dmc.data(), dofmap_coarse, sizeof(int32_t) * h_dmc.size(),
+                         hipMemcpyDeviceToHost, s));
+  PMG_HIP(hipStreamSynchronize(s));
+
+  // launch index of every patch
+  std::vector<int32_t> launch_of(np, 0);
+  for (size_t l = 0; l < v.launch_first->size(); ++l)
+    for (int q = 0; q < (*v.launch_count)[l]; ++q)
+      launch_of[(*v.launch_first)[l] + q] = (int32_t)l;
+
+  std::vector<int32_t> cpoff(np + 1, 0), clmap_id(np, 0), first(nc_total, INT32_MAX);
+  std::vector<uint32_t> cpdofs;
+  std::vector<uint16_t> clmaps;
+  std::map<std::vector<uint16_t>, int32_t> uniq;
+  std::vector<std::vector<int32_t>> lists(np);
+  int cmax = 1;
+  for (int p = 0; p < np; ++p)
+  {
+    std::vector<int32_t>& d = lists[p];
+    const int nc = (*v.pncell_h)[p];
+    for (int sl = 0; sl < nc; ++sl)
+    {
+      const int32_t cell = (*v.pcell_h)[(size_t)p * K + sl];
+      PMG_REQUIRE(cell >= 0 && cell < ncells, "pmg_interpolator_create_with_operator: cell out of range");
+      for (int k = 0; k < Nc; ++k)
+      {
+        const int32_t dof = h_dmc[(size_t)cell * Nc + k];
+        PMG_REQUIRE(dof >= 0 && dof < nc_total, "coarse dofmap entry %d out of range", dof);
+        d.push_back(dof);
+      }
+    }
+    std::sort(d.begin(), d.end());
+    d.erase(std::unique(d.begin(), d.end()), d.end());
+    PMG_REQUIRE(d.size() <= 65535, "coarse patch too large");
+    cmax = std::max(cmax, (int)d.size());
+    for (int32_t dof : d)
+      first[dof] = std::min(first[dof], launch_of[p]);
+  }
+  for (int p = 0; p < np; ++p)
+  {
+    const std::vector<int32_t>& d = lists[p];
+    for (int32_t dof : d)
+      cpdofs.push_back((uint32_t)dof | (first[dof] != launch_of[p] ? PD_ACC : 0u));
+    cpoff[p + 1] = (int32_t)cpdofs.size();
+    std::vector<uint16_t> lm((size_t)K * Nc, 0);
+    const int nc = (*v.pncell_h)[p];
+    for (int sl = 0; sl < nc; ++sl)
+    {
+      const int32_t cell = (*v.pcell_h)[(size_t)p * K + sl];
+      for (int k = 0; k < Nc; ++k)
+        lm[(size_t)sl * Nc + k] = (uint16_t)(
+            std::lower_bound(d.begin(), d.end(), h_dmc[(size_t)cell * Nc + k]) - d.begin());
+    }
+    auto it = uniq.find(lm);
+    if (it == uniq.end())
+    {
+      it = uniq.emplace(lm, (int32_t)uniq.size()).first;
+      clmaps.insert(clmaps.end(), lm.begin(), lm.end());
+    }
+    clmap_id[p] = it->second;
+  }
+  ip->cmax_m = cmax;
+  PMG_TRY(upload(&ip->cpoff, cpoff.data(), cpoff.size(), s));
+  PMG_TRY(upload(&ip->cpdofs, cpdofs.data(), cpdofs.size(), s));
+  PMG_TRY(upload(&ip->clmap_id, clmap_id.data(), clmap_id.size(), s));
+  PMG_TRY(upload(&ip->clmaps, clmaps.data(), clmaps.size(), s));
+  PMG_HIP(hipMalloc(&ip->pmult, v.npdofs ? v.npdofs : 1));
+  if (v.npdofs > 0)
+  {
+    long long blocks = (v.npdofs + 255) / 256;
+    patch_mult_kernel<<<(int)(blocks > 4096 ? 4096 : blocks), 256, 0, s>>>(v.npdofs, v.pdofs,
+                                                                           ip->inv_mult, ip->pmult);
+    PMG_HIP(hipGetLastError());
+  }
+  // LDS: table + coarse list + fine list + per-wave scratch
+  const int ndc = ip->ndc, ndf = ip->ndf;
+  const size_t per_wave = (size_t)ip->Nf + ndf * ndc * ndc + ndf * ndf * ndc;
+  const size_t base = (size_t)ndf * ndc + cmax + v.max_m;
+  int waves = 8;
+  while (waves > 1 && 8 * (base + waves * per_wave) > 64 * 1024)
+    --waves;
+  ip->pwaves = waves;
+  ip->pshm = 8 * (base + waves * per_wave);
+  PMG_REQUIRE(ip->pshm <= 160 * 1024, "transfer kernels need %zu bytes of LDS", ip->pshm);
+  if (ip->pshm > 48 * 1024)
+    PMG_TRY(set_patch_kernel_lds(ndc, ndf, (int)ip->pshm));
+  PMG_HIP(hipStreamSynchronize(s));
+  ip->patched = true;
+  return PMG_OK;
+}
+
+extern "C" int pmg_interpolator_interpolate_add(pmg_interpolator ip, double* coarse, double* fine,
+                                                pmg_stream stream)
+{
+  PMG_REQUIRE(ip && coarse && fine, "pmg_interpolator_interpolate_add: NULL argument");
+  if (ip->patched)
+    return interp_prolong_add(ip, coarse, fine, S(stream));
+  return fail(PMG_ERR_INVALID, "pmg_interpolator_interpolate_add needs an interpolator created "
+                               "with pmg_interpolator_create_with_operator");
+}
+
 extern "C" int pmg_interpolator_destroy(pmg_interpolator ip)
 {
   if (!ip)
     return PMG_OK;
+  (void)hipFree(ip->cpoff);
+  (void)hipFree(ip->cpdofs);
+  (void)hipFree(ip->clmap_id);
+  (void)hipFree(ip->clmaps);
+  (void)hipFree(ip->pmult);
   (void)hipFree(ip->M1);
   (void)hipFree(ip->inv_mult);
   (void)hipFree(ip->lcells);

@@ -60,6 +60,9 @@ struct pmg_laplacian_s
   uint16_t* lmaps = nullptr;   // [nuniq][K*N]
   int32_t npatch = 0;
   std::vector<int32_t> launch_first, launch_count;
+  std::vector<int32_t> pcell_h, pncell_h; // host copies for components that share the patches
+  long long npdofs = 0;
+  int max_m = 0;
   int n_launch_l = 0;
   bool needs_zero = false; // some local dof belongs to no listed cell
   double* diag_inv = nullptr; // [size_local + num_ghosts]
@@ -774,6 +777,29 @@ int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s);
 const double* laplacian_diag_inv(pmg_laplacian op) { return op->diag_inv; }
 pmg_layout laplacian_layout(pmg_laplacian op) { return op->layout; }
 long long laplacian_launches(pmg_laplacian op) { return op->applies; }
+PatchView laplacian_patches(pmg_laplacian op)
+{
+  PatchView v;
+  v.P = op->P;
+  v.K = op->K;
+  v.N = op->N;
+  v.npatch = op->npatch;
+  v.max_m = op->max_m;
+  v.column = column_layout(op->P);
+  v.pcell_h = &op->pcell_h;
+  v.pncell_h = &op->pncell_h;
+  v.launch_first = &op->launch_first;
+  v.launch_count = &op->launch_count;
+  v.n_launch_l = op->n_launch_l;
+  v.pcell = op->pcell;
+  v.pncell = op->pncell;
+  v.poff = op->poff;
+  v.pdofs = op->pdofs;
+  v.lmap_id = op->lmap_id;
+  v.lmaps = op->lmaps;
+  v.npdofs = op->npdofs;
+  return v;
+}
 
 // operator()(in, out), src/laplacian.hpp:462-482 + impl_operator :373-460
 int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s)
@@ -925,6 +951,10 @@ extern "C" int pmg_laplacian_create_with_tables(
       op->needs_zero = !touched[i];
   }
   op->npatch = plan.npatch;
+  op->pcell_h = plan.pcell;
+  op->pncell_h = plan.pncell;
+  op->npdofs = (long long)plan.pdofs.size();
+  op->max_m = plan.max_M;
   op->launch_first = plan.launch_first;
   op->launch_count = plan.launch_count;
   op->n_launch_l = plan.n_launch_l;

@@ -94,6 +94,27 @@ struct PatchPlan
   int max_M = 0;
 };
 
+// What other components (the p-transfer) need to know about an operator's patches.
+struct PatchView
+{
+  int P = 0, K = 0, N = 0, npatch = 0, max_m = 0;
+  bool column = false;
+  // host copies
+  const std::vector<int32_t>* pcell_h = nullptr;  // [npatch*K]
+  const std::vector<int32_t>* pncell_h = nullptr; // [npatch]
+  const std::vector<int32_t>* launch_first = nullptr;
+  const std::vector<int32_t>* launch_count = nullptr;
+  int n_launch_l = 0;
+  // device arrays
+  const int32_t* pcell = nullptr;
+  const int32_t* pncell = nullptr;
+  const int32_t* poff = nullptr;
+  const uint32_t* pdofs = nullptr;
+  const int32_t* lmap_id = nullptr;
+  const uint16_t* lmaps = nullptr;
+  long long npdofs = 0; // total entries of pdofs
+};
+
 // Build the plan.  `centroid` [ncells*3] drives the grouping (tensor-grid blocks
 // when the centroids form a tensor grid, Morton-ordered chunks otherwise);
 // correctness does not depend on the grouping, only the amount of sharing does.

@@ -25,6 +25,8 @@ pmg_layout laplacian_layout(pmg_laplacian op);
 long long laplacian_launches(pmg_laplacian op);
 int interp_prolong(pmg_interpolator ip, double* coarse, double* fine, hipStream_t s);
 int interp_restrict(pmg_interpolator ip, double* fine, double* coarse, hipStream_t s);
+int interp_prolong_add(pmg_interpolator ip, double* coarse, double* fine, hipStream_t s);
+bool interp_is_patched(pmg_interpolator ip);
 void launch_cheb_first(int n, double* x, double* r, double* z, const double* q, const double* dinv,
                        double c1, double c2, hipStream_t s);
 } // namespace pmg
@@ -142,9 +144,14 @@ int mg_apply(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStr
   }
   for (int i = 0; i < L - 1; ++i)
   {
-    double* du = mg->smoothers[i + 1]->q;                              // work vector as du
-    PMG_TRY(interp_prolong(mg->interps[i], mg->u[i], du, s));          // :123
-    launch_add(mg->layouts[i + 1]->size_local, mg->u[i + 1], du, s);   // :129
+    if (interp_is_patched(mg->interps[i]))
+      PMG_TRY(interp_prolong_add(mg->interps[i], mg->u[i], mg->u[i + 1], s)); // :123 + :129 in one pass
+    else
+    {
+      double* du = mg->smoothers[i + 1]->q;                            // work vector as du
+      PMG_TRY(interp_prolong(mg->interps[i], mg->u[i], du, s));        // :123
+      launch_add(mg->layouts[i + 1]->size_local, mg->u[i + 1], du, s); // :129
+    }
     const double* bi = (i + 1 == L - 1) ? rhs : mg->b[i + 1];
     PMG_TRY(cheb_solve(mg->smoothers[i + 1], mg->ops[i + 1], mg->u[i + 1], bi, false, false, s)); // :138
   }

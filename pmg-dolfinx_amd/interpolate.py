@@ -18,7 +18,7 @@ class Interpolator:
     degree."""
 
     def __init__(self, Q1_degree, Q2_degree, Q1_dofmap, Q2_dofmap, l_cells, b_cells, Q1_layout: Layout,
-                 Q2_layout: Layout):
+                 Q2_layout: Layout, fine_operator=None):
         dev = Q2_layout.device
         self.lc, self.lf = Q1_layout, Q2_layout
         self.dmc = _dev_i32(Q1_dofmap, dev)
@@ -30,9 +30,12 @@ class Interpolator:
         lc = np.ascontiguousarray(l_cells, dtype=np.int32)
         bc = np.ascontiguousarray(b_cells, dtype=np.int32)
         h = vp()
-        call("pmg_interpolator_create", C.byref(h), Q1_layout.handle, Q2_layout.handle, int(Q1_degree),
-             int(Q2_degree), ncells, ptr(self.dmc), ptr(self.dmf), lc.ctypes.data_as(_lib.c_ip), lc.size,
-             bc.ctypes.data_as(_lib.c_ip), bc.size, current_stream())
+        # with the fine-level operator the transfers share its cell patches (no atomics)
+        self._fine_operator = fine_operator
+        call("pmg_interpolator_create_with_operator", C.byref(h), Q1_layout.handle, Q2_layout.handle,
+             int(Q1_degree), int(Q2_degree), ncells, ptr(self.dmc), ptr(self.dmf), lc.ctypes.data_as(_lib.c_ip),
+             lc.size, bc.ctypes.data_as(_lib.c_ip), bc.size,
+             fine_operator.handle if fine_operator is not None else vp(0), current_stream())
         self._handle = h
 
     @property
@@ -41,6 +44,11 @@ class Interpolator:
 
     def interpolate(self, Q1_vector: Vector, Q2_vector: Vector):  # :186-239
         call("pmg_interpolator_interpolate", self._handle, ptr(Q1_vector.data), ptr(Q2_vector.data),
+             current_stream())
+
+    def interpolate_add(self, Q1_vector: Vector, Q2_vector: Vector):
+        """Q2 += P Q1 in one pass (needs ``fine_operator``)."""
+        call("pmg_interpolator_interpolate_add", self._handle, ptr(Q1_vector.data), ptr(Q2_vector.data),
              current_stream())
 
     def reverse_interpolate(self, Q2_vector: Vector, Q1_vector: Vector):  # :246-303

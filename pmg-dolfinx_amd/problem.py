@@ -85,7 +85,7 @@ class PoissonHierarchy:
             self.interpolators.append(
                 Interpolator(self.orders[i], self.orders[i + 1], self.operators[i].dofmap,
                              self.operators[i + 1].dofmap, lf.lcells, lf.bcells, self.layouts[i],
-                             self.layouts[i + 1]))
+                             self.layouts[i + 1], fine_operator=self.operators[i + 1]))
         # V-cycle, :348-355
         self.mg = MultigridPreconditioner(self.layouts, self.levels[0].bc_marker)
         self.mg.set_solvers(self.smoothers)

@@ -182,14 +182,24 @@ def test_cg_and_eigenvalues(pm):
         cg2.compute_eigenvalues()
 
 
-@pytest.mark.parametrize("pc,pf", [(1, 2), (2, 4), (1, 3), (3, 6), (4, 8)])
-def test_transfer_parity(pm, pc, pf):
+@pytest.mark.parametrize("patched", [False, True])
+@pytest.mark.parametrize("pc,pf,n,warped", [(1, 2, (3, 2, 2), True), (2, 4, (3, 2, 2), True), (1, 3, (3, 2, 2), True),
+                                            (3, 6, (3, 2, 2), True), (4, 8, (3, 2, 2), True),
+                                            (2, 4, (4, 4, 16), False), (1, 2, (4, 4, 16), False),
+                                            (1, 4, (2, 4, 8), False)])
+def test_transfer_parity(pm, pc, pf, n, warped, patched):
+    """Both transfer implementations: the cell form (reference-shaped constructor)
+    and the patch form that shares the fine operator's patches."""
     from oracle import pmg_oracle as po
 
-    part = pm.BoxPartition((3, 2, 2), warp=warp)
+    part = pm.BoxPartition(n, warp=warp if warped else None)
     lc, lf = part.level(pc), part.level(pf)
     Lc, Lf = pm.make_layout(lc), pm.make_layout(lf)
-    ip = pm.Interpolator(pc, pf, lc.dofmap, lf.dofmap, lf.lcells, lf.bcells, Lc, Lf)
+    fop = None
+    if patched:
+        fop = pm.MatFreeLaplacian(pf, 2.0, lf.dofmap, part.xgeom, part.geom_dofmap, lf.lcells, lf.bcells,
+                                  lf.bc_marker, Lf)
+    ip = pm.Interpolator(pc, pf, lc.dofmap, lf.dofmap, lf.lcells, lf.bcells, Lc, Lf, fine_operator=fop)
     oi = po.Interpolator(pc, pf, lc.dofmap, lf.dofmap, lc.ndofs, lf.ndofs)
     rng = np.random.default_rng(pc * 10 + pf)
     uc, uf = rng.standard_normal(lc.ndofs), rng.standard_normal(lf.ndofs)
@@ -202,6 +212,15 @@ def test_transfer_parity(pm, pc, pf):
     assert _relerr(vc2.data_copy(), oi.reverse_interpolate(uf)) < 1e-12
     # restriction is the transpose of prolongation
     assert abs(uf @ vf.data_copy() - vc2.data_copy() @ uc) < 1e-11 * np.abs(uf).sum()
+    if patched:  # fused correction: fine += P coarse (src/pmg.hpp:123-129)
+        vf3 = _vec(pm, Lf, uf)
+        ip.interpolate_add(vc, vf3)
+        assert _relerr(vf3.data_copy(), uf + oi.interpolate(uc)) < 1e-13
+        ip.reverse_interpolate(vf2, vc2)  # second call: no dependence on the previous content
+        assert _relerr(vc2.data_copy(), oi.reverse_interpolate(uf)) < 1e-12
+    else:
+        with pytest.raises(RuntimeError):
+            ip.interpolate_add(vc, pm.Vector(Lf))
 
 
 @pytest.mark.parametrize("orders,n", [((1, 2, 4), 4), ((1, 3), 5), ((2, 4), (3, 4, 2)), ((3,), 3)])
