@@ -169,6 +169,24 @@ def main():
         "roofline": roofline,
     }
 
+    # ---- BASELINE config 2 as worded: CG preconditioned by the V-cycle, to rtol 1e-8 (extra, not `value`) ----
+    cg = pm.CGSolver(H.layouts[-1])
+    cg.set_max_iterations(100)
+    cg.set_tolerance(1e-8)
+    xs = H.new_vector()
+    xs.set(0.0)
+    sync_all()
+    t_pcg = time.perf_counter()
+    pcg_its = cg.solve(H.operators[-1], xs, b, preconditioner=H.mg)
+    sync_all()
+    t_pcg = time.perf_counter() - t_pcg
+    rr = H.new_vector()
+    H.operators[-1](xs, rr)
+    pm.axpy(rr, -1.0, rr, b)
+    out["pcg"] = {"preconditioner": "V-cycle, zero initial guess", "rtol": 1e-8, "iterations": pcg_its,
+                  "seconds": t_pcg, "true_relative_residual": pm.norm(rr) / pm.norm(b)}
+    del cg, xs, rr
+
     # ---- CPU baseline: the C/OpenMP port of the same lean V-cycle on the host cores (rank 0, N = 1) ----
     if world == 1 and not args.no_cpu:
         from oracle import c_oracle as co

@@ -482,11 +482,15 @@ class CGSolver:
     def store_coefficients(self, v):
         self.store = bool(v)
 
-    def solve(self, A, x, b):
+    def solve(self, A, x, b, precond=None):
+        """``precond`` (optional, not in the reference): callable r -> M^-1 r that
+        replaces the hard-wired Jacobi ``pointwise_mult`` of ``:161,192`` (SURVEY.md
+        8f-3: the V-cycle from a zero initial guess)."""
         dinv = A.diag_inverse()
+        M = (lambda v: v * dinv) if precond is None else precond
         y = A.apply(x)
         r = b - y
-        p = r * dinv
+        p = M(r)
         rnorm0 = inner_product(p, r)
         rnorm = rnorm0
         rtol2 = self.rtol * self.rtol
@@ -497,7 +501,7 @@ class CGSolver:
             alpha = rnorm / inner_product(p, y)
             x += alpha * p
             r -= alpha * y
-            y = r * dinv
+            y = M(r)
             rnorm_new = inner_product(r, y)
             beta = rnorm_new / rnorm
             rnorm = rnorm_new

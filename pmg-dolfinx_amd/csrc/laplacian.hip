@@ -767,7 +767,6 @@ int upload(T** dst, const T* src, size_t n, hipStream_t s)
   return PMG_OK;
 }
 
-static_assert(Shape<4>::K == 32 && Shape<4>::ROUNDS == 8 && Shape<4>::THREADS == 512, "P = 4 patch");
 } // namespace
 
 namespace pmg

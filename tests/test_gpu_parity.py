@@ -296,3 +296,35 @@ def test_full_size_properties(pm):
     xc.data.copy_(torch.from_numpy(part.dof_coordinates(4)[:, 0].copy()))
     op(xc, y)
     assert abs(pm.inner_product(xc, y) - 2.0) < 1e-10  # u = x: u^T A u = kappa
+
+
+def test_pcg_with_vcycle_preconditioner(pm):
+    """BASELINE config 2 wording: CG preconditioned by the p-MG V-cycle (zero initial
+    guess inside the preconditioner).  Not in the reference (its CGSolver hard-wires
+    Jacobi, src/cg.hpp:154-161,192); checked against the oracle's PCG with the
+    oracle's V-cycle."""
+    from oracle import pmg_oracle as po
+
+    n, orders, k = 6, (1, 2, 4), 3
+    h = pm.PoissonHierarchy(n, orders, kappa=2.0, cheb_its=k, warp=warp)
+    mesh, ops, sm, it, mg, b, eigs = po.build_hierarchy(n, orders, cheb_its=k, warp=warp)
+    for s_, e in zip(sm, h.eig_ranges):
+        s_.eig_range = e
+    cg = pm.CGSolver(h.layouts[-1])
+    cg.set_max_iterations(50)
+    cg.set_tolerance(1e-8)
+    x = h.new_vector()
+    x.set(0.0)
+    its = cg.solve(h.operators[-1], x, h.rhs[-1], preconditioner=h.mg)
+    ocg = po.CGSolver()
+    ocg.set_max_iterations(50)
+    ocg.set_tolerance(1e-8)
+    xo = np.zeros_like(b)
+    oits = ocg.solve(ops[-1], xo, b, precond=lambda r: mg.apply(r, np.zeros_like(r)))
+    assert its == oits and its < 15
+    assert _relerr(x.data_copy(), xo) < 1e-8
+    # it really solves the system
+    r = pm.Vector(h.layouts[-1])
+    h.operators[-1](x, r)
+    pm.axpy(r, -1.0, r, h.rhs[-1])
+    assert pm.norm(r) < 1e-6 * pm.norm(h.rhs[-1])
