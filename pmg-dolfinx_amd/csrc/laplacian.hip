@@ -54,6 +54,8 @@ struct pmg_laplacian_s
   double* gweights = nullptr;  // [N]
   int32_t* pcell = nullptr;    // [npatch*K]
   int32_t* pncell = nullptr;   // [npatch]
+  int32_t* bzero = nullptr;    // dofs first written by the (atomic) boundary launch
+  int32_t n_bzero = 0;
   int32_t* poff = nullptr;     // [npatch+1]
   uint32_t* pdofs = nullptr;
   int32_t* lmap_id = nullptr;  // [npatch]
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(Shape<P>::THREADS)
                      const uint32_t* __restrict__ pdofs, const int32_t* __restrict__ lmap_id,
                      const uint16_t* __restrict__ lmaps, const int32_t* __restrict__ pcell,
                      const int32_t* __restrict__ pncell, const double* __restrict__ kappa,
-                     const double* __restrict__ Dg, int first)
+                     const double* __restrict__ Dg, int first, int atomic_out)
 {
   using Sh = Shape<P>;
   constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, CPR = Sh::CPR, ROUNDS = Sh::ROUNDS, NSQ = ND * ND;
@@ -284,7 +286,7 @@ __global__ void __launch_bounds__(Shape<P>::THREADS)
     for (int k = 0; k < ITER; ++k)
     {
       const uint32_t dof = m[k] & PD_MASK;
-      const bool acc = (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+      const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
       xv[k] = x[dof];
       const double* ya = acc ? (const double*)(y + dof) : (x + dof); // re-read of x keeps it unconditional
       yv[k] = *ya;
@@ -306,7 +308,7 @@ __global__ void __launch_bounds__(Shape<P>::THREADS)
       const int i = t + k * THREADS;
       if (i < M)
       {
-        const bool acc = (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+        const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
         sx[i] = (m[k] & PD_BC) ? 0.0 : xv[k]; // Dirichlet columns masked, src/laplacian.hpp:186-189
         sy[i] = acc ? yv[k] : 0.0;
       }
@@ -390,6 +392,8 @@ __global__ void __launch_bounds__(Shape<P>::THREADS)
         if (!(mk & PD_ACC))
           y[dof] = x[dof]; // :273-274
       }
+      else if (atomic_out)
+        atomicAdd(&y[dof], sy[i]); // merged boundary launch (global_atomic_add_f64)
       else
         y[dof] = sy[i];
     }
@@ -428,7 +432,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
                             const int32_t* __restrict__ lmap_id,
                             const uint16_t* __restrict__ lmaps, const int32_t* __restrict__ pcell,
                             const int32_t* __restrict__ pncell, const double* __restrict__ kappa,
-                            const double* __restrict__ Dg, int first)
+                            const double* __restrict__ Dg, int first, int atomic_out)
 {
   using Sh = Shape<P>;
   constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, NQ2 = Sh::NQ2, CW = Sh::CW, NW = Sh::NW;
@@ -465,7 +469,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
     for (int k = 0; k < ITER; ++k)
     {
       const uint32_t dof = m[k] & PD_MASK;
-      const bool acc = (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+      const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
       xv[k] = x[dof];
       const double* ya = acc ? (const double*)(y + dof) : (x + dof);
       yv[k] = *ya;
@@ -477,7 +481,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
       const int i = t + k * THREADS;
       if (i < M)
       {
-        const bool acc = (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+        const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
         sx[i] = (m[k] & PD_BC) ? 0.0 : xv[k]; // src/laplacian.hpp:186-189
         sy[i] = acc ? yv[k] : 0.0;
       }
@@ -624,10 +628,18 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
         if (!(mk & PD_ACC))
           y[dof] = x[dof]; // :273-274
       }
+      else if (atomic_out)
+        atomicAdd(&y[dof], sy[i]); // merged boundary launch (global_atomic_add_f64)
       else
         y[dof] = sy[i];
     }
   }
+}
+
+__global__ void zero_list_kernel(int n, const int32_t* __restrict__ idx, double* __restrict__ y)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    y[idx[i]] = 0.0;
 }
 
 // ---- matrix-free diagonal (replaces the CSR detour of examples/pmg/main.cpp:274-279) ----
@@ -702,18 +714,19 @@ __global__ void rhs_kernel(long long nslots, int nq, const int32_t* __restrict__
 
 template <int P>
 int launch_stiffness(pmg_laplacian op, const double* x, double* y, int first, int count,
-                     hipStream_t s)
+                     int atomic_out, hipStream_t s)
 {
   if (count <= 0)
     return PMG_OK;
   if constexpr (column_layout(P))
     stiffness_column_kernel<P><<<count, Shape<P>::WTHREADS, 0, s>>>(
         x, y, op->G, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell, op->pncell, op->kappa,
-        op->D, first);
+        op->D, first, atomic_out);
   else
     stiffness_kernel<P><<<count, Shape<P>::THREADS, 0, s>>>(x, y, op->G, op->poff, op->pdofs,
                                                             op->lmap_id, op->lmaps, op->pcell,
-                                                            op->pncell, op->kappa, op->D, first);
+                                                            op->pncell, op->kappa, op->D, first,
+                                                            atomic_out);
   op->launches++;
   return PMG_OK;
 }
@@ -724,31 +737,32 @@ int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, h
   for (int l = l0; l < l1; ++l)
   {
     const int first = op->launch_first[l], count = op->launch_count[l];
+    const int atomic_out = (l >= op->n_launch_l) ? 1 : 0; // the merged boundary launch
     switch (op->P)
     {
     case 1:
-      PMG_TRY(launch_stiffness<1>(op, x, y, first, count, s));
+      PMG_TRY(launch_stiffness<1>(op, x, y, first, count, atomic_out, s));
       break;
     case 2:
-      PMG_TRY(launch_stiffness<2>(op, x, y, first, count, s));
+      PMG_TRY(launch_stiffness<2>(op, x, y, first, count, atomic_out, s));
       break;
     case 3:
-      PMG_TRY(launch_stiffness<3>(op, x, y, first, count, s));
+      PMG_TRY(launch_stiffness<3>(op, x, y, first, count, atomic_out, s));
       break;
     case 4:
-      PMG_TRY(launch_stiffness<4>(op, x, y, first, count, s));
+      PMG_TRY(launch_stiffness<4>(op, x, y, first, count, atomic_out, s));
       break;
     case 5:
-      PMG_TRY(launch_stiffness<5>(op, x, y, first, count, s));
+      PMG_TRY(launch_stiffness<5>(op, x, y, first, count, atomic_out, s));
       break;
     case 6:
-      PMG_TRY(launch_stiffness<6>(op, x, y, first, count, s));
+      PMG_TRY(launch_stiffness<6>(op, x, y, first, count, atomic_out, s));
       break;
     case 7:
-      PMG_TRY(launch_stiffness<7>(op, x, y, first, count, s));
+      PMG_TRY(launch_stiffness<7>(op, x, y, first, count, atomic_out, s));
       break;
     case 8:
-      PMG_TRY(launch_stiffness<8>(op, x, y, first, count, s));
+      PMG_TRY(launch_stiffness<8>(op, x, y, first, count, atomic_out, s));
       break;
     default:
       return fail(PMG_ERR_INVALID, "Unsupported degree"); // src/laplacian.hpp:346,479
@@ -807,6 +821,9 @@ int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s)
   const int nl = (int)op->launch_first.size();
   if (op->needs_zero || nl == 0)
     PMG_HIP(hipMemsetAsync(out, 0, sizeof(double) * l->total(), s)); // :466 (else: first-writer stores)
+  if (op->n_bzero > 0 && !(op->needs_zero || nl == 0))
+    zero_list_kernel<<<(op->n_bzero + 255) / 256 > 1024 ? 1024 : (op->n_bzero + 255) / 256, 256, 0, s>>>(
+        op->n_bzero, op->bzero, out);
   PMG_TRY(pmg_scatter_fwd_begin(l, in, (pmg_stream)s));          // :378
   PMG_TRY(run_launches(op, in, out, 0, op->n_launch_l, s));      // :380-413 interior cells
   PMG_TRY(pmg_scatter_fwd_end(l, in, (pmg_stream)s));            // :425
@@ -959,6 +976,8 @@ extern "C" int pmg_laplacian_create_with_tables(
   op->n_launch_l = plan.n_launch_l;
   PMG_TRY(upload(&op->pcell, plan.pcell.data(), plan.pcell.size(), s));
   PMG_TRY(upload(&op->pncell, plan.pncell.data(), plan.pncell.size(), s));
+  op->n_bzero = (int32_t)plan.bzero.size();
+  PMG_TRY(upload(&op->bzero, plan.bzero.data(), plan.bzero.size(), s));
   PMG_TRY(upload(&op->poff, plan.poff.data(), plan.poff.size(), s));
   PMG_TRY(upload(&op->pdofs, plan.pdofs.data(), plan.pdofs.size(), s));
   PMG_TRY(upload(&op->lmap_id, plan.lmap_id.data(), plan.lmap_id.size(), s));
@@ -1005,6 +1024,7 @@ extern "C" int pmg_laplacian_destroy(pmg_laplacian op)
   (void)hipFree(op->gweights);
   (void)hipFree(op->pcell);
   (void)hipFree(op->pncell);
+  (void)hipFree(op->bzero);
   (void)hipFree(op->poff);
   (void)hipFree(op->pdofs);
   (void)hipFree(op->lmap_id);

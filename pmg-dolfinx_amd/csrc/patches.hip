@@ -119,7 +119,13 @@ void group_cells(const int32_t* cells, int32_t n, const float* centroid, PatchSh
       std::vector<int32_t> g;
       while (j < n && key[order[j]] == key[order[i]] && (int)g.size() < K)
         g.push_back(cells[order[j++]]);
-      groups.push_back(std::move(g));
+      // thin cell sets (the shell of boundary / ghost cells of a brick) leave most
+      // blocks partly empty: fold a partial block into its predecessor in key order
+      // (the next block along z, then y) while the patch still holds <= K cells
+      if (!groups.empty() && groups.back().size() + g.size() <= (size_t)K && (int)g.size() < K)
+        groups.back().insert(groups.back().end(), g.begin(), g.end());
+      else
+        groups.push_back(std::move(g));
       i = j;
     }
   }
@@ -322,6 +328,19 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
     plan.lmap_id[i] = it->second;
   }
   plan.nuniq = (int)uniq.size();
+  // merge the boundary colours into one (atomic) launch
+  if (nlaunch > plan.n_launch_l)
+  {
+    const int nl = plan.n_launch_l;
+    const int32_t bfirst = plan.launch_first[nl];
+    plan.launch_first.resize(nl + 1);
+    plan.launch_count.resize(nl + 1);
+    plan.launch_first[nl] = bfirst;
+    plan.launch_count[nl] = np - bfirst;
+    for (int32_t d = 0; d < ndofs; ++d)
+      if (first[d] != INT32_MAX && first[d] >= nl && !bc[d])
+        plan.bzero.push_back(d);
+  }
   return PMG_OK;
 }
 } // namespace pmg

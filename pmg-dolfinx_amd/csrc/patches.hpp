@@ -96,6 +96,12 @@ struct PatchPlan
   std::vector<int32_t> launch_first, launch_count;
   int n_launch_l = 0;
   int max_M = 0;
+  // The boundary cell list is a thin shell: its colours would be many small
+  // launches.  They are issued as ONE launch whose patches add their sums to y
+  // with atomics (few, in long runs); bzero lists the dofs no interior patch
+  // writes, which must be zero before that launch.  The PD_ACC flags still name a
+  // unique first patch per dof (the transfers rely on that).
+  std::vector<int32_t> bzero;
 };
 
 // What other components (the p-transfer) need to know about an operator's patches.
