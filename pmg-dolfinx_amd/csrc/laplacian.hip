@@ -503,14 +503,6 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
 #ifndef PMG_GDEPTH
 #define PMG_GDEPTH 1
 #endif
-#if defined(PMG_D_IN_LDS)
-  // the lane's table rows/columns are re-read from LDS in every layer; zl is an
-  // opaque zero that keeps the compiler from hoisting the reads into 40 registers
-#define DA(m) sD[zl + a * ND + (m)]
-#define DB(m) sD[zl + b * ND + (m)]
-#define DTA(m) sD[zl + (m) * ND + a]
-#define DTB(m) sD[zl + (m) * ND + b]
-#else
   double Da[ND], Db[ND], DTa[ND], DTb[ND]; // D[a][.], D[b][.], D[.][a], D[.][b]
 #pragma unroll
   for (int mm = 0; mm < ND; ++mm)
@@ -524,15 +516,10 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
 #define DB(m) Db[m]
 #define DTA(m) DTa[m]
 #define DTB(m) DTb[m]
-#endif
   double* q_s = sq + wave * WL + cw * NQ2;  // this cell's slices
   double* gr_s = sgr + wave * WL + cw * NQ2;
   double* gs_s = sgs + wave * WL + cw * NQ2;
-#if defined(PMG_ABL) && PMG_ABL == 7 // timing-only ablation: gather + write-back only
-  const int items = 0;
-#else
   const int items = (nc + CW - 1) / CW;
-#endif
 
   for (int it = wave; it < items; it += NW)
   {
@@ -572,10 +559,6 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
         gq[k % GD][1] = Gs[(k + GD) * 3 * NQ2 + NQ2];
         gq[k % GD][2] = Gs[(k + GD) * 3 * NQ2 + 2 * NQ2];
       }
-#if defined(PMG_D_IN_LDS)
-      int zl = 0;
-      asm volatile("" : "+v"(zl));
-#endif
       q_s[ab] = u[k];
       wave_fence();
       double qr = 0.0, qs = 0.0, qt = 0.0;

@@ -50,6 +50,41 @@ __global__ void read_waves(const double2* __restrict__ a, size_t nchunks, double
     out[0] = s;
 }
 
+// (d) skeleton of the column kernel's G stream: one workgroup of 8 waves per patch (192 KB of G),
+//     LDS_BYTES of LDS to pin the residency, wave w takes items w and w + 8, layer k + 1 in flight
+template <int LDS_BYTES, int DEPTH>
+__global__ void read_patch(const double2* __restrict__ a, double* out)
+{
+  __shared__ double lds[LDS_BYTES / 8 + 512];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (LDS_BYTES > 0)
+    lds[t] = t;
+  __syncthreads();
+  double s = LDS_BYTES > 0 ? lds[(t * 7) % 512] : 0.0;
+  const int l = lane < 50 ? lane : 49;
+  for (int it = wave; it < 16; it += 8)
+  {
+    const double2* base = a + (size_t)blockIdx.x * 12000 + (size_t)it * 750 + (l / 25) * 375 + (l % 25);
+    double2 v[DEPTH * 3];
+#pragma unroll
+    for (int d = 0; d < DEPTH * 3; ++d)
+      v[d] = base[d * 25];
+#pragma unroll
+    for (int k = 0; k < 15; k += 3)
+    {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+      {
+        s += v[(k + j) % (DEPTH * 3)].x + v[(k + j) % (DEPTH * 3)].y;
+        if (k + j + DEPTH * 3 < 15)
+          v[(k + j) % (DEPTH * 3)] = base[(k + j + DEPTH * 3) * 25];
+      }
+    }
+  }
+  if (s == 12345.678)
+    out[0] = s;
+}
+
 // (c) copy
 __global__ void copy_linear(const double2* __restrict__ a, double2* __restrict__ b, size_t n)
 {
@@ -105,5 +140,22 @@ int main()
       printf("read_waves   blocks %5d threads %4d : depth1 %6.0f GB/s  depth2 %6.0f GB/s  depth5 %6.0f GB/s\n", blocks,
              threads, bytes / ms1 / 1e6, bytes / ms2 / 1e6, bytes / ms5 / 1e6);
     }
+  {
+    const int npatch = (int)(bytes / 192000);
+    double m;
+    m = timeit([&] { read_patch<0, 1><<<npatch, 512>>>(a, out); });
+    printf("read_patch   LDS  0 KB depth1 : %7.1f us %6.0f GB/s\n", m * 1e3, bytes / m / 1e6);
+    m = timeit([&] { read_patch<53248, 1><<<npatch, 512>>>(a, out); });
+    printf("read_patch   LDS 52 KB depth1 : %7.1f us %6.0f GB/s\n", m * 1e3, bytes / m / 1e6);
+    m = timeit([&] { read_patch<53248, 2><<<npatch, 512>>>(a, out); });
+    printf("read_patch   LDS 52 KB depth2 : %7.1f us %6.0f GB/s\n", m * 1e3, bytes / m / 1e6);
+    m = timeit([&] { read_patch<53248, 5><<<npatch, 512>>>(a, out); });
+    printf("read_patch   LDS 52 KB depth5 : %7.1f us %6.0f GB/s\n", m * 1e3, bytes / m / 1e6);
+    m = timeit([&] { read_patch<32768, 1><<<npatch, 512>>>(a, out); });
+    printf("read_patch   LDS 32 KB depth1 : %7.1f us %6.0f GB/s\n", m * 1e3, bytes / m / 1e6);
+    // 8 launches of 1/8 of the patches, like the colours
+    m = timeit([&] { for (int c = 0; c < 8; ++c) read_patch<53248, 1><<<npatch / 8, 512>>>(a + (size_t)c * (npatch / 8) * 12000, out); });
+    printf("read_patch   LDS 52 KB depth1, 8 launches : %7.1f us %6.0f GB/s\n", m * 1e3, bytes / m / 1e6);
+  }
   return 0;
 }
