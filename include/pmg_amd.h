@@ -180,6 +180,14 @@ int pmg_laplacian_get_geometry(pmg_laplacian op, double* G_out, pmg_stream strea
  * b[bc] = 0.  `f` holds the nodal values of the source term. */
 int pmg_laplacian_assemble_rhs(pmg_laplacian op, const double* f, double* b, pmg_stream stream);
 int pmg_laplacian_degree(pmg_laplacian op);
+/* Geometry mode of the apply.  0 (default): the reference's data structure, the
+ * stored tensor G[cell][q][6] is streamed (48 bytes per quadrature point).
+ * 1: affine cells -- when every cell is a parallelepiped, G_q = w_q * Gc with one
+ * constant tensor per cell, so the kernel reads 48 bytes per CELL instead (same
+ * result to rounding; not in the reference; SURVEY.md 8d calls this byte model
+ * separate from storedG).  Fails if the mesh has a non-affine cell. */
+int pmg_laplacian_is_affine(pmg_laplacian op);
+int pmg_laplacian_set_geometry_mode(pmg_laplacian op, int mode);
 /* One operator application issues one stiffness-kernel launch per patch colour
  * and cell list (8 on a structured single-rank box). */
 int pmg_laplacian_launches_per_apply(pmg_laplacian op);

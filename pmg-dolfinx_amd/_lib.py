@@ -69,6 +69,8 @@ _SIGS = {
     "pmg_laplacian_get_geometry": (C.c_int, [vp, vp, vp]),
     "pmg_laplacian_assemble_rhs": (C.c_int, [vp, vp, vp, vp]),
     "pmg_laplacian_degree": (C.c_int, [vp]),
+    "pmg_laplacian_is_affine": (C.c_int, [vp]),
+    "pmg_laplacian_set_geometry_mode": (C.c_int, [vp, C.c_int]),
     "pmg_laplacian_launches_per_apply": (C.c_int, [vp]),
     "pmg_laplacian_time_kernel": (C.c_int, [vp, vp, vp, C.c_int, c_dp, vp]),
     "pmg_chebyshev_create": (C.c_int, [C.POINTER(vp), vp, C.c_double, C.c_double]),
@@ -107,7 +109,7 @@ _SIGS = {
 
 # functions whose int return value is a count, not a status
 _COUNT_FUNCS = {"pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
-                "pmg_laplacian_degree", "pmg_laplacian_launches_per_apply"}
+                "pmg_laplacian_degree", "pmg_laplacian_launches_per_apply", "pmg_laplacian_is_affine"}
 
 _lib = None
 

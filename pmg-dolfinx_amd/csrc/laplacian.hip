@@ -49,6 +49,10 @@ struct pmg_laplacian_s
   const int8_t* bc = nullptr;
   // owned
   double2* G = nullptr;        // [nslots][3][N]
+  double* Gaff = nullptr;      // [nslots][6] constant tensor K K^T / detJ of each (affine) cell
+  double* W1 = nullptr;        // [nd] 1-D GLL weights
+  bool all_affine = false;     // every listed cell is a parallelepiped
+  int geometry_mode = 0;       // 0 = stored G (reference data structure), 1 = affine cells
   double* D = nullptr;         // [nd*nd]
   double* dphi_geom = nullptr; // [3][N][8]
   double* gweights = nullptr;  // [N]
@@ -183,6 +187,55 @@ __global__ void geometry_kernel(long long nslots, int nd, int column,
   Gc[gidx(column, nd, nq, q, 0)] = make_double2(g0, g1);
   Gc[gidx(column, nd, nq, q, 1)] = make_double2(g2, g3);
   Gc[gidx(column, nd, nq, q, 2)] = make_double2(g4, g5);
+}
+
+// Constant geometry tensor of an affine cell: K K^T / detJ at the cell centre
+// (q-independent when the cell is a parallelepiped); G_q = w_q * this.
+__global__ void affine_geometry_kernel(long long nslots, const int32_t* __restrict__ pcell,
+                                       const double* __restrict__ xgeom,
+                                       const int32_t* __restrict__ geom_dofmap,
+                                       double* __restrict__ Gaff)
+{
+  long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= nslots)
+    return;
+  int c = pcell[slot];
+  double g[6] = {0, 0, 0, 0, 0, 0};
+  if (c >= 0)
+  {
+    const int32_t* gd = geom_dofmap + (size_t)c * 8;
+    const double* x0 = xgeom + 3 * (size_t)gd[0];
+    const double* xz = xgeom + 3 * (size_t)gd[1]; // (0,0,1)
+    const double* xy = xgeom + 3 * (size_t)gd[2]; // (0,1,0)
+    const double* xx = xgeom + 3 * (size_t)gd[4]; // (1,0,0)
+    double J[3][3];
+    for (int i = 0; i < 3; ++i)
+    {
+      J[i][0] = xx[i] - x0[i];
+      J[i][1] = xy[i] - x0[i];
+      J[i][2] = xz[i] - x0[i];
+    }
+    double K[3][3];
+    K[0][0] = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    K[0][1] = -J[0][1] * J[2][2] + J[0][2] * J[2][1];
+    K[0][2] = J[0][1] * J[1][2] - J[0][2] * J[1][1];
+    K[1][0] = -J[1][0] * J[2][2] + J[1][2] * J[2][0];
+    K[1][1] = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+    K[1][2] = -J[0][0] * J[1][2] + J[0][2] * J[1][0];
+    K[2][0] = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    K[2][1] = -J[0][0] * J[2][1] + J[0][1] * J[2][0];
+    K[2][2] = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    const double detJ = J[0][0] * K[0][0] + J[0][1] * K[1][0] + J[0][2] * K[2][0];
+    const double s = 1.0 / detJ;
+    g[0] = (K[0][0] * K[0][0] + K[0][1] * K[0][1] + K[0][2] * K[0][2]) * s;
+    g[1] = (K[1][0] * K[0][0] + K[1][1] * K[0][1] + K[1][2] * K[0][2]) * s;
+    g[2] = (K[2][0] * K[0][0] + K[2][1] * K[0][1] + K[2][2] * K[0][2]) * s;
+    g[3] = (K[1][0] * K[1][0] + K[1][1] * K[1][1] + K[1][2] * K[1][2]) * s;
+    g[4] = (K[2][0] * K[1][0] + K[2][1] * K[1][1] + K[2][2] * K[1][2]) * s;
+    g[5] = (K[2][0] * K[2][0] + K[2][1] * K[2][1] + K[2][2] * K[2][2]) * s;
+  }
+  for (int d = 0; d < 6; ++d)
+    Gaff[slot * 6 + d] = g[d];
 }
 
 // paired slot layout -> the reference's [cell][q][6]
@@ -424,10 +477,11 @@ __device__ __forceinline__ void wave_fence()
 #ifndef PMG_WPS
 #define PMG_WPS (P <= 4 ? (2 * Shape<P>::NW + 3) / 4 : 1)
 #endif
-template <int P>
+template <int P, bool AFF>
 __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
     stiffness_column_kernel(const double* __restrict__ x, double* __restrict__ y,
-                            const double2* __restrict__ G, const int32_t* __restrict__ poff,
+                            const double2* __restrict__ G, const double* __restrict__ Gaff,
+                            const double* __restrict__ W1, const int32_t* __restrict__ poff,
                             const uint32_t* __restrict__ pdofs,
                             const int32_t* __restrict__ lmap_id,
                             const uint16_t* __restrict__ lmaps, const int32_t* __restrict__ pcell,
@@ -516,6 +570,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
 #define DB(m) Db[m]
 #define DTA(m) DTa[m]
 #define DTB(m) DTb[m]
+  const double wab = AFF ? W1[a] * W1[b] : 0.0; // 1-D GLL weights of the lane's column
   double* q_s = sq + wave * WL + cw * NQ2;  // this cell's slices
   double* gr_s = sgr + wave * WL + cw * NQ2;
   double* gs_s = sgs + wave * WL + cw * NQ2;
@@ -531,15 +586,27 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
 #pragma unroll
     for (int k = 0; k < ND; ++k)
       l[k] = lm[k * NQ2];
-    // G layers 0 .. GD-1 in flight (empty slots hold zeros)
+    // storedG: G layers 0 .. GD-1 in flight (empty slots hold zeros).
+    // affine cells (AFF): G_q = w_a w_b w_c * Gc with one constant tensor Gc per cell.
     constexpr int GD = ND < PMG_GDEPTH ? ND : PMG_GDEPTH;
-    double2 gq[GD][3];
-#pragma unroll
-    for (int d = 0; d < GD; ++d)
+    double2 gq[AFF ? 1 : GD][3];
+    double gc[6] = {0, 0, 0, 0, 0, 0};
+    if constexpr (AFF)
     {
-      gq[d][0] = Gs[d * 3 * NQ2];
-      gq[d][1] = Gs[d * 3 * NQ2 + NQ2];
-      gq[d][2] = Gs[d * 3 * NQ2 + 2 * NQ2];
+      const double* ga = Gaff + ((size_t)p * K + slotc) * 6;
+#pragma unroll
+      for (int d = 0; d < 6; ++d)
+        gc[d] = ga[d];
+    }
+    else
+    {
+#pragma unroll
+      for (int d = 0; d < GD; ++d)
+      {
+        gq[d][0] = Gs[d * 3 * NQ2];
+        gq[d][1] = Gs[d * 3 * NQ2 + NQ2];
+        gq[d][2] = Gs[d * 3 * NQ2 + 2 * NQ2];
+      }
     }
     const double kap = skap[slotc];
     double u[ND], Aq[ND];
@@ -552,12 +619,25 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
 #pragma unroll
     for (int k = 0; k < ND; ++k)
     {
-      const double2 g01 = gq[k % GD][0], g23 = gq[k % GD][1], g45 = gq[k % GD][2];
-      if (k + GD < ND) // refill the slot with layer k + GD
+      double2 g01, g23, g45;
+      if constexpr (AFF)
       {
-        gq[k % GD][0] = Gs[(k + GD) * 3 * NQ2];
-        gq[k % GD][1] = Gs[(k + GD) * 3 * NQ2 + NQ2];
-        gq[k % GD][2] = Gs[(k + GD) * 3 * NQ2 + 2 * NQ2];
+        const double sc = wab * W1[k]; // w_a w_b w_c; W1[k] is wave-uniform (scalar load)
+        g01 = make_double2(sc * gc[0], sc * gc[1]);
+        g23 = make_double2(sc * gc[2], sc * gc[3]);
+        g45 = make_double2(sc * gc[4], sc * gc[5]);
+      }
+      else
+      {
+        g01 = gq[k % GD][0];
+        g23 = gq[k % GD][1];
+        g45 = gq[k % GD][2];
+        if (k + GD < ND) // refill the slot with layer k + GD
+        {
+          gq[k % GD][0] = Gs[(k + GD) * 3 * NQ2];
+          gq[k % GD][1] = Gs[(k + GD) * 3 * NQ2 + NQ2];
+          gq[k % GD][2] = Gs[(k + GD) * 3 * NQ2 + 2 * NQ2];
+        }
       }
       q_s[ab] = u[k];
       wave_fence();
@@ -702,9 +782,16 @@ int launch_stiffness(pmg_laplacian op, const double* x, double* y, int first, in
   if (count <= 0)
     return PMG_OK;
   if constexpr (column_layout(P))
-    stiffness_column_kernel<P><<<count, Shape<P>::WTHREADS, 0, s>>>(
-        x, y, op->G, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell, op->pncell, op->kappa,
-        op->D, first, atomic_out);
+  {
+    if (op->geometry_mode == 1)
+      stiffness_column_kernel<P, true><<<count, Shape<P>::WTHREADS, 0, s>>>(
+          x, y, op->G, op->Gaff, op->W1, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell,
+          op->pncell, op->kappa, op->D, first, atomic_out);
+    else
+      stiffness_column_kernel<P, false><<<count, Shape<P>::WTHREADS, 0, s>>>(
+          x, y, op->G, op->Gaff, op->W1, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell,
+          op->pncell, op->kappa, op->D, first, atomic_out);
+  }
   else
     stiffness_kernel<P><<<count, Shape<P>::THREADS, 0, s>>>(x, y, op->G, op->poff, op->pdofs,
                                                             op->lmap_id, op->lmaps, op->pcell,
@@ -942,6 +1029,30 @@ extern "C" int pmg_laplacian_create_with_tables(
       }
     PMG_TRY(build_patch_plan(plan, degree, ncells, h_dofmap.data(), h_bc.data(), total,
                              centroid.data(), lcells, n_lcells, bcells, n_bcells));
+    // affine (parallelepiped) cells: vertex (i,j,l) = x0 + i e1 + j e2 + l e3
+    op->all_affine = (n_lcells + n_bcells) > 0;
+    for (int set = 0; set < 2 && op->all_affine; ++set)
+    {
+      const int32_t* list = set ? bcells : lcells;
+      const int n = set ? n_bcells : n_lcells;
+      for (int i = 0; i < n && op->all_affine; ++i)
+      {
+        const int32_t* gd = h_gd.data() + (size_t)list[i] * 8;
+        const double* v[8];
+        for (int k = 0; k < 8; ++k)
+          v[k] = h_x.data() + 3 * (size_t)gd[k];
+        double diam = 0, dev = 0;
+        for (int a = 0; a < 3; ++a)
+        {
+          const double e1 = v[4][a] - v[0][a], e2 = v[2][a] - v[0][a], e3 = v[1][a] - v[0][a];
+          diam += std::fabs(e1) + std::fabs(e2) + std::fabs(e3);
+          dev += std::fabs(v[3][a] - (v[0][a] + e2 + e3)) + std::fabs(v[5][a] - (v[0][a] + e1 + e3))
+                 + std::fabs(v[6][a] - (v[0][a] + e1 + e2)) + std::fabs(v[7][a] - (v[0][a] + e1 + e2 + e3));
+        }
+        if (dev > 1e-12 * diam)
+          op->all_affine = false;
+      }
+    }
     // is every local dof written by some patch?  (else out must be zero-filled first)
     std::vector<char> touched(total, 0);
     for (uint32_t v : plan.pdofs)
@@ -968,6 +1079,11 @@ extern "C" int pmg_laplacian_create_with_tables(
 
   const long long nslots = (long long)plan.npatch * op->K;
   const long long nq_total = nslots * N;
+  PMG_TRY(upload(&op->W1, wts.data(), wts.size(), s));
+  PMG_HIP(hipMalloc(&op->Gaff, sizeof(double) * 6 * (nslots ? nslots : 1)));
+  if (nslots > 0)
+    affine_geometry_kernel<<<(unsigned)((nslots + 255) / 256), 256, 0, s>>>(nslots, op->pcell, xgeom,
+                                                                           geom_dofmap, op->Gaff);
   PMG_HIP(hipMalloc(&op->G, sizeof(double2) * 3 * (nq_total ? nq_total : 1)));
   PMG_HIP(hipMalloc(&op->diag_inv, sizeof(double) * (total ? total : 1)));
   PMG_HIP(hipEventCreate(&op->ev0));
@@ -1003,6 +1119,8 @@ extern "C" int pmg_laplacian_destroy(pmg_laplacian op)
     return PMG_OK;
   (void)hipFree(op->G);
   (void)hipFree(op->D);
+  (void)hipFree(op->Gaff);
+  (void)hipFree(op->W1);
   (void)hipFree(op->dphi_geom);
   (void)hipFree(op->gweights);
   (void)hipFree(op->pcell);
@@ -1022,6 +1140,20 @@ extern "C" int pmg_laplacian_destroy(pmg_laplacian op)
 }
 
 extern "C" int pmg_laplacian_degree(pmg_laplacian op) { return op ? op->P : -1; }
+
+extern "C" int pmg_laplacian_is_affine(pmg_laplacian op) { return op ? (op->all_affine ? 1 : 0) : -1; }
+
+extern "C" int pmg_laplacian_set_geometry_mode(pmg_laplacian op, int mode)
+{
+  PMG_REQUIRE(op && (mode == 0 || mode == 1), "pmg_laplacian_set_geometry_mode: bad argument");
+  if (mode == 1)
+  {
+    PMG_REQUIRE(op->all_affine, "pmg_laplacian_set_geometry_mode: the mesh has non-affine cells");
+    PMG_REQUIRE(column_layout(op->P), "pmg_laplacian_set_geometry_mode: affine mode needs degree <= 7");
+  }
+  op->geometry_mode = mode;
+  return PMG_OK;
+}
 
 extern "C" int pmg_laplacian_apply(pmg_laplacian op, double* in, double* out, pmg_stream stream)
 {

@@ -103,6 +103,15 @@ class MatFreeLaplacian:
     def assemble_rhs(self, f: Vector, b: Vector):
         call("pmg_laplacian_assemble_rhs", self._handle, ptr(f.data), ptr(b.data), current_stream())
 
+    def is_affine(self) -> bool:
+        """Every cell is a parallelepiped (constant Jacobian)."""
+        return bool(call("pmg_laplacian_is_affine", self._handle))
+
+    def set_geometry_mode(self, mode: str):
+        """"stored" (default, the reference's G[cell][q][6] stream) or "affine"
+        (one constant tensor per cell; needs ``is_affine()``)."""
+        call("pmg_laplacian_set_geometry_mode", self._handle, {"stored": 0, "affine": 1}[mode])
+
     def launches_per_apply(self) -> int:
         return call("pmg_laplacian_launches_per_apply", self._handle)
 

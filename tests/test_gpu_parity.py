@@ -12,7 +12,18 @@ torch = pytest.importorskip("torch")
 
 
 def warp(x):
+    """Curved grid lines, but every cell stays a parallelepiped (each coordinate is a
+    sum of 1-D functions): J varies from cell to cell, not inside a cell."""
     return x + 0.03 * np.sin(3.0 * x[:, [1, 2, 0]])
+
+
+def twist(x):
+    """Genuinely trilinear cells: J (and G) vary inside every cell."""
+    y = x.copy()
+    y[:, 0] += 0.12 * x[:, 1] * x[:, 2]
+    y[:, 1] += 0.10 * x[:, 0] * x[:, 2] + 0.05 * x[:, 0] * x[:, 1] * x[:, 2]
+    y[:, 2] += 0.08 * x[:, 0] * x[:, 1]
+    return y
 
 
 @pytest.fixture(scope="module")
@@ -32,7 +43,8 @@ def _relerr(a, b):
 def _single_level(pm, n, P, warped=True, bc=True):
     from oracle import pmg_oracle as po
 
-    part = pm.BoxPartition(n, warp=warp if warped else None)
+    wf = {True: warp, False: None, "twist": twist}[warped]
+    part = pm.BoxPartition(n, warp=wf)
     lv = part.level(P)
     bcm = lv.bc_marker if bc else np.zeros_like(lv.bc_marker)
     layout = pm.make_layout(lv)
@@ -47,10 +59,12 @@ def _vec(pm, layout, a):
     return v
 
 
+@pytest.mark.parametrize("mesh", [True, "twist"])
 @pytest.mark.parametrize("P", [1, 2, 3, 4, 5, 6, 7, 8])
-def test_apply_parity_all_degrees(pm, P):
+def test_apply_parity_all_degrees(pm, P, mesh):
     n = (3, 2, 4) if P > 4 else (5, 4, 3)
-    part, lv, layout, op, A = _single_level(pm, n, P)
+    part, lv, layout, op, A = _single_level(pm, n, P, warped=mesh)
+    assert op.is_affine() == (mesh is True)
     rng = np.random.default_rng(P)
     u = rng.standard_normal(lv.ndofs)
     x, y = _vec(pm, layout, u), pm.Vector(layout)
@@ -328,3 +342,38 @@ def test_pcg_with_vcycle_preconditioner(pm):
     h.operators[-1](x, r)
     pm.axpy(r, -1.0, r, h.rhs[-1])
     assert pm.norm(r) < 1e-6 * pm.norm(h.rhs[-1])
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 5, 6, 7])
+def test_affine_geometry_mode(pm, P):
+    """Affine cells (here a sheared, stretched box: J constant, not diagonal): the
+    constant-tensor apply equals the stored-G apply and the oracle; a mesh with a
+    non-affine cell refuses the mode."""
+    from oracle import pmg_oracle as po
+
+    shear = np.array([[1.0, 0.2, 0.1], [0.0, 0.8, 0.3], [0.1, 0.0, 1.3]])
+    lin = lambda x: x @ shear.T  # noqa: E731
+    n = (4, 4, 8) if P <= 4 else (2, 2, 4)
+    part = pm.BoxPartition(n, warp=lin)
+    lv = part.level(P)
+    layout = pm.make_layout(lv)
+    op = pm.MatFreeLaplacian(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells, lv.bc_marker, layout)
+    assert op.is_affine()
+    A = po.Laplacian(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.bc_marker)
+    u = np.random.default_rng(P).standard_normal(lv.ndofs)
+    x, y0, y1 = _vec(pm, layout, u), pm.Vector(layout), pm.Vector(layout)
+    op(x, y0)
+    op.set_geometry_mode("affine")
+    op(x, y1)
+    ref = A.apply(u)
+    assert _relerr(y0.data_copy(), ref) < 1e-12
+    assert _relerr(y1.data_copy(), ref) < 1e-12
+    op.set_geometry_mode("stored")
+    # trilinear (twisted) cells are not affine
+    part2 = pm.BoxPartition((2, 2, 2), warp=twist)
+    lv2 = part2.level(P)
+    op2 = pm.MatFreeLaplacian(P, 2.0, lv2.dofmap, part2.xgeom, part2.geom_dofmap, lv2.lcells, lv2.bcells,
+                              lv2.bc_marker, pm.make_layout(lv2))
+    assert not op2.is_affine()
+    with pytest.raises(RuntimeError, match="non-affine"):
+        op2.set_geometry_mode("affine")

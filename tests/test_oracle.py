@@ -18,6 +18,15 @@ def warp(x):
     return x + 0.03 * np.sin(3.0 * x[:, [1, 2, 0]])
 
 
+def twist(x):
+    """Genuinely trilinear cells (J varies inside a cell; detJ needs the full expansion)."""
+    y = x.copy()
+    y[:, 0] += 0.12 * x[:, 1] * x[:, 2]
+    y[:, 1] += 0.10 * x[:, 0] * x[:, 2] + 0.05 * x[:, 0] * x[:, 1] * x[:, 2]
+    y[:, 2] += 0.08 * x[:, 0] * x[:, 1]
+    return y
+
+
 @pytest.fixture(scope="module")
 def golden():
     with open(os.path.join(HERE, "golden", "tqli_golden.json")) as f:
@@ -63,14 +72,18 @@ def test_p1_is_seven_point_stencil(built):
         assert np.abs(A.apply(np.ones(U.size))).max() < 1e-13  # KAT 2: null space
 
 
+@pytest.mark.parametrize("wf", [warp, twist])
 @pytest.mark.parametrize("P", [1, 2, 3, 4, 6, 8])
-def test_matfree_equals_assembled_and_c(P, built):
+def test_matfree_equals_assembled_and_c(P, wf, built):
     """KATs 4, 5, 6, 10 and numpy == C: symmetry, mat-free vs own CSR (mirror of
     --mat_comp, examples/mat_free/main.cpp:270-289), diagonal, BC semantics."""
     n = 2 if P > 4 else 3
-    m = po.BoxMesh(n, warp=warp)
+    m = po.BoxMesh(n, warp=wf)
     bc = m.boundary_marker(P)
     A = po.Laplacian(P, 2.0, m.dofmap(P), m.xgeom, m.geom_dofmap, bc)
+    if wf is twist:  # the volume of the twisted box from the quadrature of detJ (exact: detJ is a polynomial
+        # of degree <= 2 per direction only for P >= 2; here just positivity and variation inside cells)
+        assert A.detJ.min() > 0 and np.ptp(A.detJ[0]) > 1e-3
     Cl = co.CLevel(P, 2.0, m.dofmap(P), m.xgeom, m.geom_dofmap, bc)
     rng = np.random.default_rng(P)
     u, v = rng.standard_normal(A.ndofs), rng.standard_normal(A.ndofs)

@@ -16,4 +16,8 @@ op.time_kernel(x, v, 3)
 ms = op.time_kernel(x, v, reps) * op.launches_per_apply()
 N, U = (P + 1) ** 3, P ** 3
 alg = (52 * N + 8 + 17 * U) * part.ncells
-print(f"lib={os.environ.get('PMG_AMD_LIB','default')} P={P} n={n} kernel {ms*1e3:.1f} us  algorithmic {alg/ms/1e6:.0f} GB/s  ({alg/ms/1e6/8000:.3f} of 8 TB/s)")
+if os.environ.get("PMG_GEOMETRY") == "affine":
+    op.set_geometry_mode("affine")
+    op.time_kernel(x, v, 3)
+    ms = op.time_kernel(x, v, reps) * op.launches_per_apply()
+print(f"geom={os.environ.get('PMG_GEOMETRY','stored')} lib={os.environ.get('PMG_AMD_LIB','default')} P={P} n={n} kernel {ms*1e3:.1f} us  algorithmic {alg/ms/1e6:.0f} GB/s  ({alg/ms/1e6/8000:.3f} of 8 TB/s)")
