@@ -83,7 +83,7 @@ def test_matfree_equals_assembled_and_c(P, wf, built):
     A = po.Laplacian(P, 2.0, m.dofmap(P), m.xgeom, m.geom_dofmap, bc)
     if wf is twist:  # the volume of the twisted box from the quadrature of detJ (exact: detJ is a polynomial
         # of degree <= 2 per direction only for P >= 2; here just positivity and variation inside cells)
-        assert A.detJ.min() > 0 and np.ptp(A.detJ[0]) > 1e-3
+        assert A.detJ.min() > 0 and np.ptp(A.detJ[0]) > 1e-5 * A.detJ[0].mean()
     Cl = co.CLevel(P, 2.0, m.dofmap(P), m.xgeom, m.geom_dofmap, bc)
     rng = np.random.default_rng(P)
     u, v = rng.standard_normal(A.ndofs), rng.standard_normal(A.ndofs)
