@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--kernel-reps", type=int, default=20)
+    ap.add_argument("--no-affine", action="store_true", help="skip the extra affine-geometry measurement")
     args = ap.parse_args()
 
     import numpy as np
@@ -136,7 +137,8 @@ def main():
             traffic = json.load(open(tfile)).get(f"stiffness_p{P}_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": f"stiffness_kernel<{P}>", "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": f"stiffness_column_kernel<{P}>" if P <= 7 else f"stiffness_kernel<{P}>",
+                "byte_model": "storedG (SURVEY.md 8d): 48N + 4N + 8 + 17U bytes per cell", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": round(kernel_ms, 5), "cells_per_launch": ncells_launch,
@@ -186,6 +188,45 @@ def main():
     out["pcg"] = {"preconditioner": "V-cycle, zero initial guess", "rtol": 1e-8, "iterations": pcg_its,
                   "seconds": t_pcg, "true_relative_residual": pm.norm(rr) / pm.norm(b)}
     del cg, xs, rr
+
+    # ---- extra, reported separately and never mixed into `value`/`roofline`: the same V-cycle with the
+    # affine-cell geometry mode (one constant tensor per cell instead of the stored G stream; byte model
+    # "cellG" = 4N + 56 + 17U bytes per cell).  Every cell of a box mesh is a parallelepiped.
+    if not args.no_affine and all(o.is_affine() and o.degree <= 7 for o in H.operators):
+        for o in H.operators:
+            o.set_geometry_mode("affine")
+        xa = H.new_vector()
+        xa.set(0.0)
+        for _ in range(args.warmup + 1):  # x above has seen warmup + steps + 1 cycles
+            H.mg.apply(b, xa)
+        sync_all()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            H.mg.apply(b, xa)
+        sync_all()
+        ta = time.perf_counter() - ta
+        if world > 1:
+            tt = torch.tensor([ta], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ta = float(tt.item())
+        op.time_kernel(u, y, 3)
+        kms = op.time_kernel(u, y, args.kernel_reps)
+        N_, U_ = (P + 1) ** 3, P**3
+        cellg = (4 * N_ + 56 + 17 * U_) * ncells_launch
+        # same iterates as the stored-G cycle?  (x after warmup+steps cycles from 0 in both modes)
+        out["affine_geometry"] = {
+            "value": fine_dofs_global * args.steps / ta, "unit": "DoF/s", "ms_per_step": 1e3 * ta / args.steps,
+            "note": "same V-cycle, geometry mode 'affine' (not the reference's data structure); not `value`",
+            "roofline": {"bound": "hbm", "byte_model": "cellG: 4N + 56 + 17U bytes per cell",
+                         "achieved": round(cellg / (kms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(cellg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(kms, 5)},
+            "max_rel_diff_vs_stored": float((xa.data[: H.levels[-1].size_local]
+                                             - x.data[: H.levels[-1].size_local]).abs().max()
+                                            / x.data[: H.levels[-1].size_local].abs().max()),
+        }
+        for o in H.operators:
+            o.set_geometry_mode("stored")
+        del xa
 
     # ---- CPU baseline: the C/OpenMP port of the same lean V-cycle on the host cores (rank 0, N = 1) ----
     if world == 1 and not args.no_cpu:

@@ -85,6 +85,23 @@ __global__ void read_patch(const double2* __restrict__ a, double* out)
     out[0] = s;
 }
 
+// (e) block tail: every workgroup busy-waits `spin` wall-clock ticks (100 MHz counter), then writes
+//     NST x 512 x 8 bytes and exits; 52 KB of LDS pins 2 workgroups per CU
+template <int NST>
+__global__ void store_tail(double* __restrict__ y, int spin_ticks)
+{
+  __shared__ double lds[53248 / 8];
+  lds[threadIdx.x] = threadIdx.x;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin_ticks)
+    __builtin_amdgcn_s_sleep(8);
+  double v = lds[(threadIdx.x * 7) % 512];
+#pragma unroll
+  for (int k = 0; k < NST; ++k)
+    y[(size_t)blockIdx.x * (NST * 512) + k * 512 + threadIdx.x] = v + k;
+}
+
 // (c) copy
 __global__ void copy_linear(const double2* __restrict__ a, double2* __restrict__ b, size_t n)
 {
@@ -156,6 +173,16 @@ int main()
     // 8 launches of 1/8 of the patches, like the colours
     m = timeit([&] { for (int c = 0; c < 8; ++c) read_patch<53248, 1><<<npatch / 8, 512>>>(a + (size_t)c * (npatch / 8) * 12000, out); });
     printf("read_patch   LDS 52 KB depth1, 8 launches : %7.1f us %6.0f GB/s\n", m * 1e3, bytes / m / 1e6);
+  }
+  {
+    double* y = (double*)b;
+    for (int spin : {500, 1000, 2000})
+    {
+      double m0 = timeit([&] { store_tail<0><<<8192, 512>>>(y, spin); });
+      double m6 = timeit([&] { store_tail<6><<<8192, 512>>>(y, spin); });
+      printf("store_tail   spin %5.1f us : no stores %7.1f us, 6 stores/thread %7.1f us (+%5.2f us per workgroup round)\n",
+             spin / 100.0, m0 * 1e3, m6 * 1e3, (m6 - m0) * 1e3 / 16.0);
+    }
   }
   return 0;
 }
