@@ -47,11 +47,14 @@ __global__ void unpack_add_kernel(int n, const int32_t* __restrict__ idx,
 }
 
 // ---- generic element-wise launcher: F::apply(i, args...) on doubles ----
+// pairs [0, n2) plus, when `tail` >= 0, the single trailing element (odd lengths)
 template <typename F>
-__global__ void ew_kernel2(int n2, F f)
+__global__ void ew_kernel2(int n2, int tail, F f)
 {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += gridDim.x * blockDim.x)
     f.pair(i);
+  if (tail >= 0 && blockIdx.x == 0 && threadIdx.x == 0)
+    f.one(tail);
 }
 template <typename F>
 __global__ void ew_kernel1(int begin, int n, F f)
@@ -67,11 +70,8 @@ void ew_launch(int n, bool vec_ok, F f, hipStream_t s)
     return;
   if (vec_ok)
   {
-    int n2 = n / 2;
-    if (n2 > 0)
-      ew_kernel2<<<ew_blocks(n2), EW_THREADS, 0, s>>>(n2, f);
-    if (n & 1)
-      ew_kernel1<<<1, 64, 0, s>>>(n - 1, n, f);
+    const int n2 = n / 2;
+    ew_kernel2<<<ew_blocks(n2), EW_THREADS, 0, s>>>(n2, (n & 1) ? n - 1 : -1, f);
   }
   else
     ew_kernel1<<<ew_blocks(n), EW_THREADS, 0, s>>>(0, n, f);
