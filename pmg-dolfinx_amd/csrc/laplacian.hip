@@ -453,6 +453,10 @@ __global__ void __launch_bounds__(Shape<P>::THREADS)
   }
 }
 
+#ifdef PMG_STAMPS
+__device__ unsigned long long* pmg_stamp_buf = nullptr;
+#endif
+
 // ---- the hot kernel, column form (P <= 7) --------------------------------------
 //
 // One workgroup per patch, NW wavefronts.  Phase 0 / write-back as in the block
@@ -502,6 +506,9 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
 
   const int p = first + blockIdx.x;
   const int t = threadIdx.x;
+#ifdef PMG_STAMPS // diagnostic build only: wall-clock stamps (100 MHz) of the phases of every workgroup
+  unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int off = poff[p];
   const int M = poff[p + 1] - off; // 1 <= M <= MAXM
   const int table = lmap_id[p];
@@ -546,6 +553,9 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
       skap[i] = (i == t) ? kapk : kappa[pcell[(size_t)p * K + i] >= 0 ? pcell[(size_t)p * K + i] : 0];
   }
   lds_barrier();
+#ifdef PMG_STAMPS
+  unsigned long long st1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- cell loop: each wave on its own
   const int wave = t >> 6, lane = t & 63;
@@ -676,6 +686,9 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
       atomicAdd(&sy[l[k]], contributes ? Aq[k] : 0.0); // :270,277 -- in LDS (ds_add_f64)
   }
   lds_barrier();
+#ifdef PMG_STAMPS
+  unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- write back (plain stores; the accumulator started from the earlier colours' y)
 #pragma unroll
@@ -697,8 +710,19 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
         y[dof] = sy[i];
     }
   }
+#ifdef PMG_STAMPS
+  __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): stores acknowledged
+  unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
+  if (t == 0 && pmg_stamp_buf)
+  {
+    unsigned long long* o = pmg_stamp_buf + (size_t)p * 4;
+    o[0] = st0;
+    o[1] = st1;
+    o[2] = st2;
+    o[3] = st3;
+  }
+#endif
 }
-
 __global__ void zero_list_kernel(int n, const int32_t* __restrict__ idx, double* __restrict__ y)
 {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -1258,3 +1282,11 @@ extern "C" int pmg_laplacian_launches_per_apply(pmg_laplacian op)
 {
   return op ? (int)op->launch_first.size() : -1;
 }
+
+#ifdef PMG_STAMPS
+extern "C" int pmg_debug_set_stamp_buffer(unsigned long long* buf)
+{
+  PMG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pmg_stamp_buf), &buf, sizeof(buf)));
+  return PMG_OK;
+}
+#endif
