@@ -71,3 +71,22 @@ def test_missing_library_fails_loudly(built, monkeypatch):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("loading a missing library must raise")
+
+
+def test_cpp_adapter_drivers_build_and_fail_loudly_without_gpu(built):
+    """include/pmg_amd.hpp compiles (build() does that for the two drivers of
+    examples/); without a GPU a driver stops with the library's error, it has no
+    other path to fall back to."""
+    import subprocess
+
+    import torch
+
+    root = os.path.dirname(HERE)
+    for name in ("mat_free_main", "pmg_main"):
+        exe = os.path.join(root, "pmg-dolfinx_amd", "bin", name)
+        assert os.path.exists(exe)
+        assert subprocess.run([exe, "--help"], capture_output=True, timeout=60).returncode == 0
+    if not torch.cuda.is_available():
+        r = subprocess.run([os.path.join(root, "pmg-dolfinx_amd", "bin", "mat_free_main"), "--n", "2"],
+                           capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and "error:" in r.stderr

@@ -1,0 +1,88 @@
+"""The C++ drivers over the adapter header (examples/, include/pmg_amd.hpp) against
+the oracle: the same runs as the reference's examples/mat_free/main.cpp and
+examples/pmg/main.cpp, executed as separate processes that link libpmg_amd.so."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "pmg-dolfinx_amd", "bin")
+
+
+def run(exe, *args):
+    path = os.path.join(BIN, exe)
+    assert os.path.exists(path), f"{path} missing: run __graft_entry__.build()"
+    r = subprocess.run([path, *map(str, args)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def grab(pattern, text):
+    return [float(v) for v in re.findall(pattern, text)]
+
+
+@pytest.mark.parametrize("n,P", [(16, 1), (5, 4), (3, 7)])
+def test_mat_free_driver(built, n, P):
+    from oracle import pmg_oracle as po
+
+    out = run("mat_free_main", "--n", n, "--degree", P, "--nreps", 5, *(["--mat_comp"] if P == 1 else []))
+    mesh = po.BoxMesh(n)
+    A = po.Laplacian(P, 2.0, mesh.dofmap(P), mesh.xgeom, mesh.geom_dofmap, mesh.boundary_marker(P))
+    u = np.ones(A.ndofs)
+    y = A.apply(u)
+    (nu,) = grab(r"Norm of u = (\S+)", out)
+    (ny,) = grab(r"Norm of y = (\S+)", out)
+    assert abs(nu - np.linalg.norm(u)) < 1e-12 * nu
+    assert abs(ny - np.linalg.norm(y)) < 1e-12 * ny  # tolerance: 1e-12 relative per apply
+    if P == 1:
+        (err,) = grab(r"Norm of error = (\S+)", out)
+        assert err < 1e-12  # the P=1 operator is the 7-point stencil (KAT 1)
+
+
+def test_pmg_driver(built):
+    from oracle import pmg_oracle as po
+
+    n, orders, k, cycles = 6, (1, 2, 4), 3, 4
+    out = run("pmg_main", "--n", n, "--orders", ",".join(map(str, orders)), "--smoother-its", k, "--cycles", cycles,
+              "--pcg")
+    lam = grab(r"Eigenvalues level \d+: \S+ - (\S+)", out)
+    rn = grab(r"Cycle \d+: residual norm = (\S+)", out)
+    (nb,) = grab(r"Norm of b = (\S+)", out)
+    (nx,) = grab(r"Norm of x = (\S+)\n", out)[:1]
+    assert len(lam) == len(orders) and len(rn) == cycles
+
+    mesh, ops, sm, it, mg, b, eigs = po.build_hierarchy(n, orders, cheb_its=k)
+    for got, ref in zip(lam, eigs):
+        assert abs(1.1 * got - ref[1]) < 1e-8 * ref[1]
+    for s, l in zip(sm, lam):  # same smoother bounds, so only the cycle arithmetic is compared
+        s.eig_range = (0.1 * l, 1.1 * l)
+    assert abs(nb - np.linalg.norm(b)) < 1e-12 * nb
+    x = np.zeros_like(b)
+    for c in range(cycles):
+        x = mg.apply(b, x, compute_rnorm=True)
+        assert abs(rn[c] - mg.rnorm) < 1e-8 * mg.rnorm + 1e-13, (c, rn[c], mg.rnorm)
+    assert abs(nx - np.linalg.norm(x)) < 1e-10 * nx  # tolerance: 1e-10 after full V-cycles
+    assert rn[-1] < 1e-2 * rn[0]
+
+    m = re.search(r"PCG with V-cycle preconditioner: (\d+) iterations, \|b - A x\| / \|b\| = (\S+), "
+                  r"Norm of x = (\S+)", out)
+    its = int(m.group(1))
+    assert 1 <= its <= 15 and float(m.group(2)) < 1e-6
+    # converged solution of A x = b, independent of the path taken
+    cg = po.CGSolver()
+    cg.set_max_iterations(2000)
+    cg.set_tolerance(1e-13)
+    xs = np.zeros_like(b)
+    cg.solve(ops[-1], xs, b)
+    assert abs(float(m.group(3)) - np.linalg.norm(xs)) < 1e-6 * np.linalg.norm(xs)
+
+
+def test_driver_errors(built):
+    path = os.path.join(BIN, "mat_free_main")
+    r = subprocess.run([path, "--degree", "9"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Unsupported degree" in r.stderr  # src/laplacian.hpp:346
