@@ -39,7 +39,7 @@ class Layout:
     """
 
     def __init__(self, size_local, num_ghosts=0, neighbors=(), send_counts=(), recv_counts=(), send_indices=None,
-                 recv_indices=None, group=None, device="cuda"):
+                 recv_indices=None, group=None, device="cuda", always_exchange=False):
         import torch
 
         self.size_local = int(size_local)
@@ -73,12 +73,14 @@ class Layout:
         self._world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         # every rank of a multi-rank group takes part in every exchange (a collective),
         # even one that happens to share no dof with anybody
-        self.distributed = self._world > 1
+        # (always_exchange: also on a single-rank group, e.g. a rank that is its own
+        # periodic neighbour -- used to exercise the RCCL branch on one GPU)
+        self.distributed = self._world > 1 or (always_exchange and dist.is_initialized())
         self._staged = self.distributed and dist.get_backend(group) != "nccl"
         self._splits()
         # callbacks must outlive the handle
         self._cb_exchange = _lib.EXCHANGE_FN(self._exchange) if self.distributed else _lib.EXCHANGE_FN()
-        self._cb_allreduce = _lib.ALLREDUCE_FN(self._allreduce) if self._world > 1 else _lib.ALLREDUCE_FN()
+        self._cb_allreduce = _lib.ALLREDUCE_FN(self._allreduce) if self.distributed else _lib.ALLREDUCE_FN()
         h = vp()
         call("pmg_layout_create", C.byref(h), self.size_local, self.num_ghosts, n_send, ptr(self.send_indices),
              ptr(self.send_buffer), n_recv, ptr(self.recv_indices), ptr(self.recv_buffer), self._cb_exchange,

@@ -105,3 +105,72 @@ def test_two_ranks_one_gpu(dims, n, built):
             assert abs(got[1] - ref[1]) < 1e-8 * ref[1]
         for e, rn in out["vcycle_err"]:
             assert e < 1e-10 and rn < 1e-8
+
+
+def _rccl_worker(port, q):
+    """One rank, nccl (= RCCL) process group: the rank is its own neighbour, so the
+    production exchange branch (async all_to_all_single on RCCL's stream, wait on the
+    compute stream) and the device all-reduce run for real on the one GPU."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        import pmg_dolfinx_amd as pm
+
+        rng = np.random.default_rng(5)
+        n, m = 100_000, 30_000
+        send = rng.permutation(n)[:m].astype(np.int32)
+        layout = pm.Layout(n, m, neighbors=[0], send_counts=[m], recv_counts=[m], send_indices=send,
+                           recv_indices=np.arange(m, dtype=np.int32), always_exchange=True)
+        assert layout.distributed and not layout._staged
+        out = {}
+        side = torch.cuda.Stream()
+        for name, stream in (("default", torch.cuda.current_stream()), ("side", side)):
+            with torch.cuda.stream(stream):
+                x = pm.Vector(layout)
+                a = rng.standard_normal(n + m)
+                x.data.copy_(torch.from_numpy(a))
+                for _ in range(3):  # repeated begin/end pairs reuse the staging buffers
+                    x.scatter_fwd_begin()
+                    pm.scale(x, 1.0)  # work enqueued between begin and end, like the interior cells
+                    x.scatter_fwd_end()
+                got = x.data_copy()
+                out[name + "_fwd"] = bool(np.array_equal(got[n:], a[send]) and np.array_equal(got[:n], a[:n]))
+                # reverse: ghosts accumulate into their owners
+                x.scatter_rev_begin()
+                x.scatter_rev_end()
+                ref = a[:n].copy()
+                np.add.at(ref, send, a[send])
+                out[name + "_rev"] = float(np.abs(x.data_copy()[:n] - ref).max())
+                out[name + "_dot"] = abs(pm.inner_product(x, x) - ref @ ref) / (ref @ ref)
+        # a hierarchy under an initialised RCCL group still runs (single brick: no exchange partners)
+        H = pm.PoissonHierarchy(4, (1, 2), cheb_its=2)
+        v = H.new_vector()
+        v.set(0.0)
+        out["rnorm"] = H.mg.apply(H.rhs[-1], v, verbose=True)
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_branch_single_rank(built):
+    import torch
+    import torch.multiprocessing as mp
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    for s in ("default", "side"):
+        assert out[s + "_fwd"]
+        assert out[s + "_rev"] < 1e-14 and out[s + "_dot"] < 1e-13
+    assert np.isfinite(out["rnorm"]) and out["rnorm"] > 0

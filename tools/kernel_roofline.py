@@ -2,7 +2,7 @@
 operator apply for p in {1..8} at ~17 M dofs (BASELINE config 4), and on the
 config-2 hierarchy (64^3, p = 4 -> 2 -> 1) the BLAS-1 ops, the Chebyshev smoother,
 the transfers and one V-cycle.  Timing: torch.cuda events on the launch stream,
-R repetitions.  Writes profiles/kernel_roofline_<tag>.md.
+R repetitions.  Writes gpurun_out/kernel_roofline_<tag>.md (copy it into profiles/).
 usage (on the GPU box): python tools/kernel_roofline.py [tag]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -88,7 +88,8 @@ counts = H.mg.apply_counts()
 nb = sum(c * apply_bytes(P, H.part.ncells) for c, P in zip(counts, (1, 2, 4)))
 add("V-cycle p=4->2->1 (applies only counted)", nb, t, f"applies per level (coarse->fine) {counts}; vector/transfer bytes not counted")
 
-out = os.path.join(ROOT, "profiles", f"kernel_roofline_{tag}.md")
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+out = os.path.join(ROOT, "gpurun_out", f"kernel_roofline_{tag}.md")  # copy into profiles/ afterwards
 with open(out, "w") as f:
     f.write(f"# Achieved HBM GB/s per kernel, round tag {tag} (MI355X, peak 8000 GB/s, copy ceiling ~6300)\n\n")
     f.write("Bytes are ALGORITHMIC (SURVEY.md 8d): compulsory traffic of the reference-faithful data structures, "
