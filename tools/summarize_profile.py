@@ -46,7 +46,7 @@ for k in sorted(fetch):
     fk = sum(fetch[k]) / len(fetch[k])
     wk = sum(write.get(k, [0])) / max(len(write.get(k, [0])), 1)
     lines.append(f"| `{k.strip()[-60:]}` | {len(fetch[k])} | {fk:.0f} | {wk:.0f} |")
-    if "stiffness_column_kernel<4>" in k:
+    if "stiffness_column_kernel<4, false>" in k:
         raw = (fk + wk) * 1024
         corrected = raw + g_bytes / 2
         out["stiffness_p4_fetch_kb_raw"] = fk
