@@ -137,7 +137,7 @@ def main():
             traffic = json.load(open(tfile)).get(f"stiffness_p{P}_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": f"stiffness_column_kernel<{P}>" if P <= 7 else f"stiffness_kernel<{P}>",
+    roofline = {"bound": "hbm", "kernel": f"stiffness_column_kernel<{P}>",
                 "byte_model": "storedG (SURVEY.md 8d): 48N + 4N + 8 + 17U bytes per cell", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
@@ -192,7 +192,7 @@ def main():
     # ---- extra, reported separately and never mixed into `value`/`roofline`: the same V-cycle with the
     # affine-cell geometry mode (one constant tensor per cell instead of the stored G stream; byte model
     # "cellG" = 4N + 56 + 17U bytes per cell).  Every cell of a box mesh is a parallelepiped.
-    if not args.no_affine and all(o.is_affine() and o.degree <= 7 for o in H.operators):
+    if not args.no_affine and all(o.is_affine() for o in H.operators):
         for o in H.operators:
             o.set_geometry_mode("affine")
         xa = H.new_vector()

@@ -96,12 +96,17 @@ struct Shape
   // column kernel: a wave takes CW whole cells, a lane one (a, b) column
   static constexpr int NQ2 = ND * ND;
   static constexpr int CW = NQ2 <= 64 ? 64 / NQ2 : 1;
+  static constexpr int WPC = (NQ2 + 63) / 64;      // waves that share one cell (2 at P = 8)
   static constexpr int ITEMS = (K + CW - 1) / CW;  // wave-items per full patch
 #ifdef PMG_NW
-  static constexpr int NW = ITEMS < PMG_NW ? ITEMS : PMG_NW; // waves per workgroup (tuning build)
+  static constexpr int NWMAX = PMG_NW; // tuning build
 #else
-  static constexpr int NW = ITEMS < 8 ? ITEMS : 8; // waves per workgroup
+  // measured (profiles/kernel_roofline): 4 waves and more workgroups per CU for the
+  // register-heavy degrees, 8 waves otherwise
+  static constexpr int NWMAX = (P == 5 || P == 6 || P == 8) ? 4 : 8;
 #endif
+  static constexpr int NG = ITEMS < NWMAX / WPC ? ITEMS : NWMAX / WPC; // items in flight per workgroup
+  static constexpr int NW = NG * WPC;                                  // waves per workgroup
   static constexpr int WTHREADS = NW * 64;
   static constexpr int WITER = (MAXM + WTHREADS - 1) / WTHREADS;
   static_assert(K % CPR == 0, "rounds must tile the patch");
@@ -282,8 +287,11 @@ __device__ __forceinline__ void lds_barrier()
 // their contributions into the LDS accumulator; the last phase writes the patch
 // dofs back.  The G stream of round r+1 is issued at the top of round r and stays
 // in flight across the LDS-only barriers (two rounds of operands are kept in flight).
+#ifndef PMG_BLOCK_WPS
+#define PMG_BLOCK_WPS 1
+#endif
 template <int P>
-__global__ void __launch_bounds__(Shape<P>::THREADS)
+__global__ void __launch_bounds__(Shape<P>::THREADS, PMG_BLOCK_WPS)
     stiffness_kernel(const double* __restrict__ x, double* __restrict__ y,
                      const double2* __restrict__ G, const int32_t* __restrict__ poff,
                      const uint32_t* __restrict__ pdofs, const int32_t* __restrict__ lmap_id,
@@ -457,7 +465,7 @@ __global__ void __launch_bounds__(Shape<P>::THREADS)
 __device__ unsigned long long* pmg_stamp_buf = nullptr;
 #endif
 
-// ---- the hot kernel, column form (P <= 7) --------------------------------------
+// ---- the hot kernel, column form --------------------------------------
 //
 // One workgroup per patch, NW wavefronts.  Phase 0 / write-back as in the block
 // kernel.  In between every wavefront works on its own: it takes CW whole cells
@@ -478,8 +486,11 @@ __device__ __forceinline__ void wave_fence()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef PMG_WPS_HI
+#define PMG_WPS_HI 1
+#endif
 #ifndef PMG_WPS
-#define PMG_WPS (P <= 4 ? (2 * Shape<P>::NW + 3) / 4 : 1)
+#define PMG_WPS (P <= 4 ? (2 * Shape<P>::NW + 3) / 4 : PMG_WPS_HI)
 #endif
 template <int P, bool AFF>
 __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
@@ -493,16 +504,16 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
                             const double* __restrict__ Dg, int first, int atomic_out)
 {
   using Sh = Shape<P>;
-  constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, NQ2 = Sh::NQ2, CW = Sh::CW, NW = Sh::NW;
+  constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, NQ2 = Sh::NQ2, CW = Sh::CW, NG = Sh::NG, WPC = Sh::WPC;
   constexpr int MAXM = Sh::MAXM, THREADS = Sh::WTHREADS, ITER = Sh::WITER;
-  constexpr int WL = CW * NQ2; // lanes of a wave that hold a column
+  constexpr int WL = CW * NQ2; // columns of one item (a wave, or WPC waves sharing a cell)
   __shared__ double sD[ND * ND];
   __shared__ double skap[K];
   __shared__ double sx[MAXM];
   __shared__ double sy[MAXM];
-  __shared__ double sq[NW * WL];
-  __shared__ double sgr[NW * WL];
-  __shared__ double sgs[NW * WL];
+  __shared__ double sq[NG * WL];
+  __shared__ double sgr[NG * WL];
+  __shared__ double sgs[NG * WL];
 
   const int p = first + blockIdx.x;
   const int t = threadIdx.x;
@@ -558,7 +569,10 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
 #endif
 
   // ---- cell loop: each wave on its own
-  const int wave = t >> 6, lane = t & 63;
+  // (nd^2 > 64, i.e. P = 8: WPC waves share a cell, the slices are exchanged between
+  // them, so the fences inside the layer loop become workgroup barriers and every
+  // wave runs the same number of items)
+  const int wave = (t >> 6) / WPC, lane = (t & 63) + 64 * ((t >> 6) % WPC);
   const bool lane_ok = lane < WL;
   const int lw = lane_ok ? lane : WL - 1;
   const int cw = lw / NQ2;          // cell of this lane inside the wave item
@@ -567,26 +581,44 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
 #ifndef PMG_GDEPTH
 #define PMG_GDEPTH 1
 #endif
+  // The lane's rows / columns of the 1-D table: in registers (4 nd doubles) for the
+  // low degrees; from degree DLDS_FROM on they are re-read from LDS in every layer, which
+  // frees 8 nd VGPRs for one more wave per SIMD (zl is an opaque zero that keeps the
+  // compiler from hoisting the reads back into registers).
+#ifndef PMG_DLDS_FROM
+#define PMG_DLDS_FROM 9
+#endif
+  constexpr bool DLDS = P >= PMG_DLDS_FROM;
   double Da[ND], Db[ND], DTa[ND], DTb[ND]; // D[a][.], D[b][.], D[.][a], D[.][b]
-#pragma unroll
-  for (int mm = 0; mm < ND; ++mm)
+  if constexpr (!DLDS)
   {
-    Da[mm] = sD[a * ND + mm];
-    Db[mm] = sD[b * ND + mm];
-    DTa[mm] = sD[mm * ND + a];
-    DTb[mm] = sD[mm * ND + b];
+#pragma unroll
+    for (int mm = 0; mm < ND; ++mm)
+    {
+      Da[mm] = sD[a * ND + mm];
+      Db[mm] = sD[b * ND + mm];
+      DTa[mm] = sD[mm * ND + a];
+      DTb[mm] = sD[mm * ND + b];
+    }
   }
-#define DA(m) Da[m]
-#define DB(m) Db[m]
-#define DTA(m) DTa[m]
-#define DTB(m) DTb[m]
+  int zl = 0;
+#define DA(m) (DLDS ? sD[zl + a * ND + (m)] : Da[m])
+#define DB(m) (DLDS ? sD[zl + b * ND + (m)] : Db[m])
+#define DTA(m) (DLDS ? sD[zl + (m) * ND + a] : DTa[m])
+#define DTB(m) (DLDS ? sD[zl + (m) * ND + b] : DTb[m])
   const double wab = AFF ? W1[a] * W1[b] : 0.0; // 1-D GLL weights of the lane's column
   double* q_s = sq + wave * WL + cw * NQ2;  // this cell's slices
   double* gr_s = sgr + wave * WL + cw * NQ2;
   double* gs_s = sgs + wave * WL + cw * NQ2;
-  const int items = (nc + CW - 1) / CW;
+  const int items = WPC > 1 ? ((nc + NG - 1) / NG) * NG : (nc + CW - 1) / CW;
+  auto slice_sync = [] {
+    if constexpr (WPC > 1)
+      lds_barrier();
+    else
+      wave_fence();
+  };
 
-  for (int it = wave; it < items; it += NW)
+  for (int it = wave; it < items; it += NG)
   {
     const int slot = it * CW + cw;
     const int slotc = slot < K ? slot : K - 1;
@@ -649,8 +681,10 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
           gq[k % GD][2] = Gs[(k + GD) * 3 * NQ2 + 2 * NQ2];
         }
       }
+      if constexpr (DLDS)
+        asm volatile("" : "+v"(zl));
       q_s[ab] = u[k];
-      wave_fence();
+      slice_sync();
       double qr = 0.0, qs = 0.0, qt = 0.0;
 #pragma unroll
       for (int mm = 0; mm < ND; ++mm)
@@ -664,7 +698,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
       const double ft = kap * (g23.x * qr + g45.x * qs + g45.y * qt); // :235
       gr_s[ab] = fr;
       gs_s[ab] = fs;
-      wave_fence();
+      slice_sync();
       double acc = 0.0;
 #pragma unroll
       for (int mm = 0; mm < ND; ++mm)
@@ -674,7 +708,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
         Aq[mm] += Dg[k * ND + mm] * ft;     // :263-267
       }
       Aq[k] += acc;
-      wave_fence();
+      slice_sync();
     }
     // Every lane adds (no branch: a conditional here lets the compiler sink the
     // whole accumulation into it and keep every layer's operands live); lanes
@@ -1173,7 +1207,7 @@ extern "C" int pmg_laplacian_set_geometry_mode(pmg_laplacian op, int mode)
   if (mode == 1)
   {
     PMG_REQUIRE(op->all_affine, "pmg_laplacian_set_geometry_mode: the mesh has non-affine cells");
-    PMG_REQUIRE(column_layout(op->P), "pmg_laplacian_set_geometry_mode: affine mode needs degree <= 7");
+    PMG_REQUIRE(column_layout(op->P), "pmg_laplacian_set_geometry_mode: affine mode needs the column kernel");
   }
   op->geometry_mode = mode;
   return PMG_OK;

@@ -66,12 +66,17 @@ inline constexpr PatchShape patch_shape(int P)
   }
 }
 
-// Two kernel families consume the patches.  "column" (P <= 7): one wavefront
-// takes whole cells, a lane owns the column of nd points above (a, b) -- the
-// per-cell tables are then stored layer by layer, index c*nd^2 + a*nd + b.
-// "block" (P = 8, 81 columns do not fit a 64-lane wave): one thread per
-// (cell, dof), tables in the dofmap order t = a*nd^2 + b*nd + c.
-inline constexpr bool column_layout(int P) { return P <= 7; }
+// Two kernel families consume the patches.  "column" (the default for every
+// degree): a wavefront takes whole cells -- at P = 8, where the 81 columns do not
+// fit 64 lanes, two wavefronts share a cell -- and a lane owns the column of nd
+// points above (a, b); the per-cell tables are then stored layer by layer, index
+// c*nd^2 + a*nd + b.  "block" (degrees above PMG_COLUMN_MAX; kept as the
+// alternative build -DPMG_COLUMN_MAX=7 for P = 8): one thread per (cell, dof),
+// tables in the dofmap order t = a*nd^2 + b*nd + c.
+#ifndef PMG_COLUMN_MAX
+#define PMG_COLUMN_MAX 8
+#endif
+inline constexpr bool column_layout(int P) { return P <= PMG_COLUMN_MAX; }
 inline int table_index(bool column, int nd, int t)
 {
   if (!column)

@@ -344,7 +344,7 @@ def test_pcg_with_vcycle_preconditioner(pm):
     assert pm.norm(r) < 1e-6 * pm.norm(h.rhs[-1])
 
 
-@pytest.mark.parametrize("P", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_affine_geometry_mode(pm, P):
     """Affine cells (here a sheared, stretched box: J constant, not diagonal): the
     constant-tensor apply equals the stored-G apply and the oracle; a mesh with a

@@ -1,15 +1,16 @@
 """Diagnostic (needs a -DPMG_STAMPS build, tools/build_ablation.sh stamps "-DPMG_STAMPS"):
-wall-clock phase durations inside the workgroups of the P=4 stiffness kernel."""
+wall-clock phase durations inside the workgroups of the column stiffness kernel.
+usage: PMG_AMD_LIB=tools/abl/libpmg_amd_stamps.so python tools/stamp_phases.py [P n cells_per_patch]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import pmg_dolfinx_amd as pm
-P, n = 4, 64
+P, n, K = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (4, 64, 32)))
 part = pm.BoxPartition(n); lv = part.level(P); layout = pm.make_layout(lv)
 op = pm.MatFreeLaplacian(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells, lv.bc_marker, layout)
 x, y = pm.Vector(layout), pm.Vector(layout)
 x.data.copy_(torch.randn(lv.ndofs, dtype=torch.float64, device="cuda"))
-npatch = part.ncells // 32
+npatch = part.ncells // K
 buf = torch.zeros(npatch * 4, dtype=torch.int64, device="cuda")
 L = pm._lib.lib()
 L.pmg_debug_set_stamp_buffer.argtypes = [C.c_void_p]
