@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-affine", action="store_true", help="skip the extra affine-geometry measurement")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the operator-apply sweep over degrees (N = 1 only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -228,6 +229,33 @@ def main():
             o.set_geometry_mode("stored")
         del xa
 
+    # ---- BASELINE config 4 (extra, N = 1): operator apply alone for p in {2, 4, 6, 8} at ~17 M dofs, same
+    # byte model and timing hook as `roofline` ----
+    if world == 1 and not args.no_sweep:
+        sweep = {}
+        for Ps, ns in ((2, 128), (4, 64), (6, 43), (8, 32)):
+            if Ps == P and ns == args.n:
+                sweep[f"p{Ps}"] = {"cells": ns**3, "dofs": fine_dofs_global, "apply_ms": roofline["apply_ms"],
+                                   "achieved": roofline["achieved"], "frac": roofline["frac"]}
+                continue
+            parts = pm.BoxPartition(ns)
+            lvs = parts.level(Ps)
+            lays = pm.make_layout(lvs)
+            ops = pm.MatFreeLaplacian(Ps, 2.0, lvs.dofmap, parts.xgeom, parts.geom_dofmap, lvs.lcells, lvs.bcells,
+                                      lvs.bc_marker, lays)
+            us, ys = pm.Vector(lays), pm.Vector(lays)
+            us.data.copy_(torch.randn(lvs.ndofs, dtype=torch.float64, device="cuda",
+                                      generator=torch.Generator(device="cuda").manual_seed(0)))
+            ops.time_kernel(us, ys, 3)
+            ms = ops.time_kernel(us, ys, args.kernel_reps) * ops.launches_per_apply()
+            gbs = algorithmic_bytes_per_cell(Ps) * parts.ncells / (ms * 1e-3) / 1e9
+            sweep[f"p{Ps}"] = {"cells": ns**3, "dofs": lvs.ndofs, "apply_ms": round(ms, 5), "achieved": round(gbs, 1),
+                               "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            del ops, us, ys, lays, lvs, parts
+            torch.cuda.empty_cache()
+        out["degree_sweep"] = {"note": "operator apply only, model storedG, GB/s of 8000 (BASELINE config 4); not `value`",
+                               **sweep}
+
     # ---- CPU baseline: the C/OpenMP port of the same lean V-cycle on the host cores (rank 0, N = 1) ----
     if world == 1 and not args.no_cpu:
         from oracle import c_oracle as co
@@ -241,14 +269,14 @@ def main():
         bh = b.data_copy()
         xc = np.zeros_like(bh)
         cm.apply(bh, xc)  # first cycle from x0 = 0: also the parity check below
-        ncpu = 2
+        ncpu = 4
         tc = time.perf_counter()
         for _ in range(ncpu):
             cm.apply(bh, xc)
         cpu_s = (time.perf_counter() - tc) / ncpu
         log(f"cpu baseline: setup {time.time() - t0 - cpu_s * ncpu:.1f}s, {cpu_s:.2f}s per V-cycle on "
             f"{co.num_threads()} threads")
-        # parity in the same run: 3 GPU V-cycles from x0 = 0 against the 3 CPU ones
+        # parity in the same run: 1 + ncpu GPU V-cycles from x0 = 0 against the CPU ones
         xg = H.new_vector()
         xg.set(0.0)
         for _ in range(1 + ncpu):
@@ -260,7 +288,7 @@ def main():
                                "kind": "port",
                                "sample": f"{ncpu} V-cycles of the same workload ({args.n}^3 hexes, "
                                          f"{fine_dofs_global} fine dofs), C/OpenMP oracle, after 1 warm-up cycle"}
-        out["parity"] = {"gpu_vs_cpu_oracle_rel_err_after_3_cycles": err, "tolerance": 1e-10}
+        out["parity"] = {f"gpu_vs_cpu_oracle_rel_err_after_{1 + ncpu}_cycles": err, "tolerance": 1e-10}
         if not err < 1e-10:
             log(f"PARITY FAILURE: {err}")
             out["parity"]["failed"] = True

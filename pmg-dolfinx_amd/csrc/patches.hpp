@@ -44,9 +44,17 @@ inline constexpr PatchShape patch_shape(int P)
   switch (P)
   {
   case 1:
+#ifdef PMG_P1_SHAPE
+    return PMG_P1_SHAPE; // tuning build
+#else
     return {4, 4, 8, 32, 256};   // M = 5*5*9   = 225
+#endif
   case 2:
+#ifdef PMG_P2_SHAPE
+    return PMG_P2_SHAPE; // tuning build
+#else
     return {4, 4, 8, 8, 1408};   // M = 9*9*17  = 1377 (measured 12 % faster than 2x2x8)
+#endif
   case 3:
     return {2, 2, 8, 4, 1280};   // M = 7*7*25  = 1225
   case 4:
