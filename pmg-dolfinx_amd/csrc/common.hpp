@@ -56,6 +56,29 @@ struct Table
 };
 } // namespace pmg
 
+// Destroys a half-built handle when a constructor returns early through
+// PMG_REQUIRE / PMG_TRY / PMG_HIP; release() hands the finished handle over.
+template <typename H>
+struct HandleGuard
+{
+  H h;
+  int (*destroy)(H);
+  HandleGuard(H handle, int (*d)(H)) : h(handle), destroy(d) {}
+  HandleGuard(const HandleGuard&) = delete;
+  HandleGuard& operator=(const HandleGuard&) = delete;
+  ~HandleGuard()
+  {
+    if (h)
+      destroy(h);
+  }
+  H release()
+  {
+    H t = h;
+    h = nullptr;
+    return t;
+  }
+};
+
 struct pmg_layout_s
 {
   int32_t size_local = 0, num_ghosts = 0, n_send = 0, n_recv = 0;

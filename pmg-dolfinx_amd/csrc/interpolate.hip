@@ -558,6 +558,7 @@ extern "C" int pmg_interpolator_create(pmg_interpolator* out, pmg_layout layout_
                 "pmg_interpolator_create: bcells out of range");
   hipStream_t s = S(stream);
   auto* ip = new pmg_interpolator_s;
+  HandleGuard<pmg_interpolator> guard(ip, pmg_interpolator_destroy);
   ip->lc = layout_coarse;
   ip->lf = layout_fine;
   ip->pc = degree_coarse;
@@ -602,7 +603,7 @@ extern "C" int pmg_interpolator_create(pmg_interpolator* out, pmg_layout layout_
     PMG_HIP(hipGetLastError());
   }
   PMG_HIP(hipStreamSynchronize(s));
-  *out = ip;
+  *out = guard.release();
   return PMG_OK;
 }
 
@@ -618,6 +619,8 @@ extern "C" int pmg_interpolator_create_with_operator(
   if (!fine_operator)
     return PMG_OK;
   pmg_interpolator ip = *out;
+  *out = nullptr; // handed back only when the patch data below is complete
+  HandleGuard<pmg_interpolator> guard(ip, pmg_interpolator_destroy);
   hipStream_t s = S(stream);
   PMG_REQUIRE(laplacian_layout(fine_operator) == layout_fine,
               "pmg_interpolator_create_with_operator: operator is not on the fine layout");
@@ -718,6 +721,7 @@ extern "C" int pmg_interpolator_create_with_operator(
     PMG_TRY(set_patch_kernel_lds(ndc, ndf, (int)ip->pshm));
   PMG_HIP(hipStreamSynchronize(s));
   ip->patched = true;
+  *out = guard.release();
   return PMG_OK;
 }
 

@@ -486,6 +486,32 @@ __device__ __forceinline__ void wave_fence()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Cache policy.  The G stream is read exactly once per application and is ~6x larger
+// than the MALL: it is loaded non-temporally (nt bit) so that it does not displace x, y,
+// the dof lists and the shared tables from L2 / MALL, and the write-back stores of y are
+// non-temporal as well.  Measured at P = 4, 64^3: 505 -> 475 us with nt stores, -> 430 us
+// with nt G loads on top; the sc0 / sc1 bits make no difference; nt on the x / y gathers
+// or on the dof lists is slower.  -DPMG_NO_NT restores the default policy (tuning build).
+// At P = 1 (8 quadrature points per cell, every dof shared by 8 cells) the default
+// policy is faster (1610 vs 1750 us at 256^3), so the hint starts at P = 2.
+#ifdef PMG_NO_NT
+#define PMG_NT_FROM 99
+#else
+#define PMG_NT_FROM 2
+#endif
+typedef double gvec2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 gload(const double2* p)
+{
+  if constexpr (NT)
+  {
+    gvec2 v = __builtin_nontemporal_load(reinterpret_cast<const gvec2*>(p));
+    return make_double2(v.x, v.y);
+  }
+  else
+    return *p;
+}
+
 #ifndef PMG_WPS_HI
 #define PMG_WPS_HI 1
 #endif
@@ -507,6 +533,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
   constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, NQ2 = Sh::NQ2, CW = Sh::CW, NG = Sh::NG, WPC = Sh::WPC;
   constexpr int MAXM = Sh::MAXM, THREADS = Sh::WTHREADS, ITER = Sh::WITER;
   constexpr int WL = CW * NQ2; // columns of one item (a wave, or WPC waves sharing a cell)
+  constexpr bool NT = P >= PMG_NT_FROM; // streaming cache policy for G and the y write-back
   __shared__ double sD[ND * ND];
   __shared__ double skap[K];
   __shared__ double sx[MAXM];
@@ -645,9 +672,9 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
 #pragma unroll
       for (int d = 0; d < GD; ++d)
       {
-        gq[d][0] = Gs[d * 3 * NQ2];
-        gq[d][1] = Gs[d * 3 * NQ2 + NQ2];
-        gq[d][2] = Gs[d * 3 * NQ2 + 2 * NQ2];
+        gq[d][0] = gload<NT>(Gs + d * 3 * NQ2);
+        gq[d][1] = gload<NT>(Gs + d * 3 * NQ2 + NQ2);
+        gq[d][2] = gload<NT>(Gs + d * 3 * NQ2 + 2 * NQ2);
       }
     }
     const double kap = skap[slotc];
@@ -676,9 +703,9 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
         g45 = gq[k % GD][2];
         if (k + GD < ND) // refill the slot with layer k + GD
         {
-          gq[k % GD][0] = Gs[(k + GD) * 3 * NQ2];
-          gq[k % GD][1] = Gs[(k + GD) * 3 * NQ2 + NQ2];
-          gq[k % GD][2] = Gs[(k + GD) * 3 * NQ2 + 2 * NQ2];
+          gq[k % GD][0] = gload<NT>(Gs + (k + GD) * 3 * NQ2);
+          gq[k % GD][1] = gload<NT>(Gs + (k + GD) * 3 * NQ2 + NQ2);
+          gq[k % GD][2] = gload<NT>(Gs + (k + GD) * 3 * NQ2 + 2 * NQ2);
         }
       }
       if constexpr (DLDS)
@@ -741,7 +768,12 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
       else if (atomic_out)
         atomicAdd(&y[dof], sy[i]); // merged boundary launch (global_atomic_add_f64)
       else
-        y[dof] = sy[i];
+      {
+        if constexpr (NT)
+          __builtin_nontemporal_store(sy[i], &y[dof]);
+        else
+          y[dof] = sy[i];
+      }
     }
   }
 #ifdef PMG_STAMPS
@@ -996,6 +1028,7 @@ extern "C" int pmg_laplacian_create_with_tables(
 
   hipStream_t s = S(stream);
   auto* op = new pmg_laplacian_s;
+  HandleGuard<pmg_laplacian> guard(op, pmg_laplacian_destroy);
   op->layout = layout;
   op->P = degree;
   op->nd = degree + 1;
@@ -1155,7 +1188,7 @@ extern "C" int pmg_laplacian_create_with_tables(
     PMG_HIP(hipGetLastError());
   }
   PMG_HIP(hipStreamSynchronize(s)); // plan's host vectors are released on return
-  *out = op;
+  *out = guard.release();
   return PMG_OK;
 }
 

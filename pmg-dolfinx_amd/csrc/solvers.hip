@@ -169,13 +169,14 @@ extern "C" int pmg_chebyshev_create(pmg_chebyshev* out, pmg_layout layout, doubl
   PMG_REQUIRE(out && layout, "pmg_chebyshev_create: NULL argument");
   PMG_REQUIRE(eig_max > 0.0, "pmg_chebyshev_create: eig_max must be positive");
   auto* sm = new pmg_chebyshev_s;
+  HandleGuard<pmg_chebyshev> guard(sm, pmg_chebyshev_destroy);
   sm->layout = layout;
   sm->eig_min = eig_min;
   sm->eig_max = eig_max;
   PMG_TRY(alloc_vec(layout, &sm->r));
   PMG_TRY(alloc_vec(layout, &sm->z));
   PMG_TRY(alloc_vec(layout, &sm->q));
-  *out = sm;
+  *out = guard.release();
   return PMG_OK;
 }
 
@@ -209,11 +210,12 @@ extern "C" int pmg_cg_create(pmg_cg* out, pmg_layout layout)
 {
   PMG_REQUIRE(out && layout, "pmg_cg_create: NULL argument");
   auto* cg = new pmg_cg_s;
+  HandleGuard<pmg_cg> guard(cg, pmg_cg_destroy);
   cg->layout = layout;
   PMG_TRY(alloc_vec(layout, &cg->r));
   PMG_TRY(alloc_vec(layout, &cg->y));
   PMG_TRY(alloc_vec(layout, &cg->p));
-  *out = cg;
+  *out = guard.release();
   return PMG_OK;
 }
 
@@ -376,6 +378,7 @@ extern "C" int pmg_multigrid_create(pmg_multigrid* out, int nlevels, const pmg_l
   PMG_REQUIRE(out && layouts && nlevels >= 1, "pmg_multigrid_create: bad argument");
   PMG_REQUIRE(bc_marker_coarsest, "pmg_multigrid_create: NULL bc marker");
   auto* mg = new pmg_multigrid_s;
+  HandleGuard<pmg_multigrid> guard(mg, pmg_multigrid_destroy);
   mg->L = nlevels;
   mg->layouts.assign(layouts, layouts + nlevels);
   mg->bc0 = bc_marker_coarsest;
@@ -387,7 +390,7 @@ extern "C" int pmg_multigrid_create(pmg_multigrid* out, int nlevels, const pmg_l
     PMG_TRY(alloc_vec(layouts[i], &mg->u[i]));
     PMG_TRY(alloc_vec(layouts[i], &mg->b[i]));
   }
-  *out = mg;
+  *out = guard.release();
   return PMG_OK;
 }
 
