@@ -252,13 +252,25 @@ __global__ void prolong_patch_kernel(TransferArgs A, const double* __restrict__ 
     tfence();
   }
   tbarrier();
-  for (int i = t; i < Mf; i += blockDim.x)
+  for (int i0 = t; i0 < Mf; i0 += 4 * blockDim.x)
   {
-    const uint32_t m = A.pdofs[off + i];
-    if (!(m & PD_ACC)) // this patch is the first (only) writer of the dof
+    uint32_t m[4];
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
     {
-      const uint32_t d = m & PD_MASK;
-      fine[d] = add ? fine[d] + sf[i] : sf[i]; // src/interpolate.hpp:42 (+ src/pmg.hpp:129 when add)
+      const int i = i0 + k * blockDim.x;
+      m[k] = A.pdofs[off + (i < Mf ? i : Mf - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      v[k] = add ? fine[m[k] & PD_MASK] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      const int i = i0 + k * blockDim.x;
+      if (i < Mf && !(m[k] & PD_ACC)) // this patch is the first (only) writer of the dof
+        fine[m[k] & PD_MASK] = v[k] + sf[i]; // src/interpolate.hpp:42 (+ src/pmg.hpp:129 when add)
     }
   }
 }
@@ -280,8 +292,32 @@ __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__
   const int nc = A.pncell[p];
   for (int i = t; i < ndf * ndc; i += blockDim.x)
     sM[i] = A.M1[i];
-  for (int i = t; i < Mf; i += blockDim.x)
-    sf[i] = fine[A.pdofs[off + i] & PD_MASK] / (double)A.pmult[off + i]; // src/interpolate.hpp:81-82
+  // four independent (index -> value) load chains per thread and pass; clamped indices
+  // keep every load unconditional
+  for (int i0 = t; i0 < Mf; i0 += 4 * blockDim.x)
+  {
+    uint32_t m[4];
+    uint8_t mu[4];
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      const int i = i0 + k * blockDim.x;
+      const int ic = off + (i < Mf ? i : Mf - 1);
+      m[k] = A.pdofs[ic];
+      mu[k] = A.pmult[ic];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      v[k] = fine[m[k] & PD_MASK];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      const int i = i0 + k * blockDim.x;
+      if (i < Mf)
+        sf[i] = v[k] / (double)mu[k]; // src/interpolate.hpp:81-82
+    }
+  }
   for (int i = t; i < Mc; i += blockDim.x)
   {
     const uint32_t m = A.cpdofs[coff + i];
