@@ -182,6 +182,7 @@ __device__ __forceinline__ int ftab(int column, int ndf, int a, int b, int c)
 struct TransferArgs
 {
   int first, ndc, ndf, column, K, max_mf, max_mc;
+  int nt; // stream the fine vector (nt loads): its level does not fit the MALL anyway
   const int32_t *poff, *lmap_id, *pncell, *cpoff, *clmap_id;
   const uint32_t *pdofs, *cpdofs;
   const uint16_t *lmaps, *clmaps;
@@ -264,7 +265,7 @@ __global__ void prolong_patch_kernel(TransferArgs A, const double* __restrict__ 
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      v[k] = add ? fine[m[k] & PD_MASK] : 0.0;
+      v[k] = !add ? 0.0 : A.nt ? __builtin_nontemporal_load(fine + (m[k] & PD_MASK)) : fine[m[k] & PD_MASK];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
@@ -309,7 +310,7 @@ __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      v[k] = fine[m[k] & PD_MASK];
+      v[k] = A.nt ? __builtin_nontemporal_load(fine + (m[k] & PD_MASK)) : fine[m[k] & PD_MASK];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
@@ -464,6 +465,11 @@ TransferArgs make_args(pmg_interpolator ip, int first)
   A.K = ip->fv.K;
   A.max_mf = ip->fv.max_m;
   A.max_mc = ip->cmax_m;
+#ifdef PMG_NO_NT
+  A.nt = 0;
+#else
+  A.nt = ip->lf->total() >= (4 << 20) ? 1 : 0; // same rule as the smoother kernels (vector.hip)
+#endif
   A.poff = ip->fv.poff;
   A.lmap_id = ip->fv.lmap_id;
   A.pncell = ip->fv.pncell;
