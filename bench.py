@@ -39,6 +39,27 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+class extra:
+    """An extra measurement must never cost the headline line: a failure inside the block is
+    logged and recorded under its key instead of propagating."""
+
+    def __init__(self, out, key):
+        self.out, self.key = out, key
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is not None and issubclass(et, Exception):
+            import traceback
+
+            log(f"extra measurement '{self.key}' failed:")
+            traceback.print_exception(et, ev, tb, file=sys.stderr)
+            self.out[self.key] = {"error": f"{et.__name__}: {ev}"}
+            return True
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,125 +194,147 @@ def main():
     }
 
     # ---- BASELINE config 2 as worded: CG preconditioned by the V-cycle, to rtol 1e-8 (extra, not `value`) ----
-    cg = pm.CGSolver(H.layouts[-1])
-    cg.set_max_iterations(100)
-    cg.set_tolerance(1e-8)
-    xs = H.new_vector()
-    xs.set(0.0)
-    sync_all()
-    t_pcg = time.perf_counter()
-    pcg_its = cg.solve(H.operators[-1], xs, b, preconditioner=H.mg)
-    sync_all()
-    t_pcg = time.perf_counter() - t_pcg
-    rr = H.new_vector()
-    H.operators[-1](xs, rr)
-    pm.axpy(rr, -1.0, rr, b)
-    out["pcg"] = {"preconditioner": "V-cycle, zero initial guess", "rtol": 1e-8, "iterations": pcg_its,
-                  "seconds": t_pcg, "true_relative_residual": pm.norm(rr) / pm.norm(b)}
-    del cg, xs, rr
+    def _pcg():
+        cg = pm.CGSolver(H.layouts[-1])
+        cg.set_max_iterations(100)
+        cg.set_tolerance(1e-8)
+        xs = H.new_vector()
+        xs.set(0.0)
+        sync_all()
+        t_pcg = time.perf_counter()
+        pcg_its = cg.solve(H.operators[-1], xs, b, preconditioner=H.mg)
+        sync_all()
+        t_pcg = time.perf_counter() - t_pcg
+        rr = H.new_vector()
+        H.operators[-1](xs, rr)
+        pm.axpy(rr, -1.0, rr, b)
+        out["pcg"] = {"preconditioner": "V-cycle, zero initial guess", "rtol": 1e-8, "iterations": pcg_its,
+                      "seconds": t_pcg, "true_relative_residual": pm.norm(rr) / pm.norm(b)}
+        del cg, xs, rr
+
+    with extra(out, "pcg"):
+        _pcg()
 
     # ---- extra, reported separately and never mixed into `value`/`roofline`: the same V-cycle with the
     # affine-cell geometry mode (one constant tensor per cell instead of the stored G stream; byte model
     # "cellG" = 4N + 56 + 17U bytes per cell).  Every cell of a box mesh is a parallelepiped.
-    if not args.no_affine and all(o.is_affine() for o in H.operators):
-        for o in H.operators:
-            o.set_geometry_mode("affine")
-        xa = H.new_vector()
-        xa.set(0.0)
-        for _ in range(args.warmup + 1):  # x above has seen warmup + steps + 1 cycles
-            H.mg.apply(b, xa)
-        sync_all()
-        ta = time.perf_counter()
-        for _ in range(args.steps):
-            H.mg.apply(b, xa)
-        sync_all()
-        ta = time.perf_counter() - ta
-        if world > 1:
-            tt = torch.tensor([ta], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            ta = float(tt.item())
-        op.time_kernel(u, y, 3)
-        kms = op.time_kernel(u, y, args.kernel_reps)
-        N_, U_ = (P + 1) ** 3, P**3
-        cellg = (4 * N_ + 56 + 17 * U_) * ncells_launch
-        # same iterates as the stored-G cycle?  (x after warmup+steps cycles from 0 in both modes)
-        out["affine_geometry"] = {
-            "value": fine_dofs_global * args.steps / ta, "unit": "DoF/s", "ms_per_step": 1e3 * ta / args.steps,
-            "note": "same V-cycle, geometry mode 'affine' (not the reference's data structure); not `value`",
-            "roofline": {"bound": "hbm", "byte_model": "cellG: 4N + 56 + 17U bytes per cell",
-                         "achieved": round(cellg / (kms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(cellg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(kms, 5)},
-            "max_rel_diff_vs_stored": float((xa.data[: H.levels[-1].size_local]
-                                             - x.data[: H.levels[-1].size_local]).abs().max()
-                                            / x.data[: H.levels[-1].size_local].abs().max()),
-        }
-        for o in H.operators:
-            o.set_geometry_mode("stored")
-        del xa
+    def _affine_geometry():
+        if not args.no_affine and all(o.is_affine() for o in H.operators):
+            for o in H.operators:
+                o.set_geometry_mode("affine")
+            try:
+                _affine_body()
+            finally:
+                for o in H.operators:
+                    o.set_geometry_mode("stored")
+
+    def _affine_body():
+        if True:
+            xa = H.new_vector()
+            xa.set(0.0)
+            for _ in range(args.warmup + 1):  # x above has seen warmup + steps + 1 cycles
+                H.mg.apply(b, xa)
+            sync_all()
+            ta = time.perf_counter()
+            for _ in range(args.steps):
+                H.mg.apply(b, xa)
+            sync_all()
+            ta = time.perf_counter() - ta
+            if world > 1:
+                tt = torch.tensor([ta], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ta = float(tt.item())
+            op.time_kernel(u, y, 3)
+            kms = op.time_kernel(u, y, args.kernel_reps)
+            N_, U_ = (P + 1) ** 3, P**3
+            cellg = (4 * N_ + 56 + 17 * U_) * ncells_launch
+            # same iterates as the stored-G cycle?  (x after warmup+steps cycles from 0 in both modes)
+            out["affine_geometry"] = {
+                "value": fine_dofs_global * args.steps / ta, "unit": "DoF/s", "ms_per_step": 1e3 * ta / args.steps,
+                "note": "same V-cycle, geometry mode 'affine' (not the reference's data structure); not `value`",
+                "roofline": {"bound": "hbm", "byte_model": "cellG: 4N + 56 + 17U bytes per cell",
+                             "achieved": round(cellg / (kms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(cellg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(kms, 5)},
+                "max_rel_diff_vs_stored": float((xa.data[: H.levels[-1].size_local]
+                                                 - x.data[: H.levels[-1].size_local]).abs().max()
+                                                / x.data[: H.levels[-1].size_local].abs().max()),
+            }
+            del xa
+
+    with extra(out, "affine_geometry"):
+        _affine_geometry()
 
     # ---- BASELINE config 4 (extra, N = 1): operator apply alone for p in {2, 4, 6, 8} at ~17 M dofs, same
     # byte model and timing hook as `roofline` ----
-    if world == 1 and not args.no_sweep:
-        sweep = {}
-        for Ps, ns in ((2, 128), (4, 64), (6, 43), (8, 32)):
-            if Ps == P and ns == args.n:
-                sweep[f"p{Ps}"] = {"cells": ns**3, "dofs": fine_dofs_global, "apply_ms": roofline["apply_ms"],
-                                   "achieved": roofline["achieved"], "frac": roofline["frac"]}
-                continue
-            parts = pm.BoxPartition(ns)
-            lvs = parts.level(Ps)
-            lays = pm.make_layout(lvs)
-            ops = pm.MatFreeLaplacian(Ps, 2.0, lvs.dofmap, parts.xgeom, parts.geom_dofmap, lvs.lcells, lvs.bcells,
-                                      lvs.bc_marker, lays)
-            us, ys = pm.Vector(lays), pm.Vector(lays)
-            us.data.copy_(torch.randn(lvs.ndofs, dtype=torch.float64, device="cuda",
-                                      generator=torch.Generator(device="cuda").manual_seed(0)))
-            ops.time_kernel(us, ys, 3)
-            ms = ops.time_kernel(us, ys, args.kernel_reps) * ops.launches_per_apply()
-            gbs = algorithmic_bytes_per_cell(Ps) * parts.ncells / (ms * 1e-3) / 1e9
-            sweep[f"p{Ps}"] = {"cells": ns**3, "dofs": lvs.ndofs, "apply_ms": round(ms, 5), "achieved": round(gbs, 1),
-                               "frac": round(gbs / HBM_PEAK_GBS, 4)}
-            del ops, us, ys, lays, lvs, parts
-            torch.cuda.empty_cache()
-        out["degree_sweep"] = {"note": "operator apply only, model storedG, GB/s of 8000 (BASELINE config 4); not `value`",
-                               **sweep}
+    def _degree_sweep():
+        if world == 1 and not args.no_sweep:
+            sweep = {}
+            for Ps, ns in ((2, 128), (4, 64), (6, 43), (8, 32)):
+                if Ps == P and ns == args.n:
+                    sweep[f"p{Ps}"] = {"cells": ns**3, "dofs": fine_dofs_global, "apply_ms": roofline["apply_ms"],
+                                       "achieved": roofline["achieved"], "frac": roofline["frac"]}
+                    continue
+                parts = pm.BoxPartition(ns)
+                lvs = parts.level(Ps)
+                lays = pm.make_layout(lvs)
+                ops = pm.MatFreeLaplacian(Ps, 2.0, lvs.dofmap, parts.xgeom, parts.geom_dofmap, lvs.lcells, lvs.bcells,
+                                          lvs.bc_marker, lays)
+                us, ys = pm.Vector(lays), pm.Vector(lays)
+                us.data.copy_(torch.randn(lvs.ndofs, dtype=torch.float64, device="cuda",
+                                          generator=torch.Generator(device="cuda").manual_seed(0)))
+                ops.time_kernel(us, ys, 3)
+                ms = ops.time_kernel(us, ys, args.kernel_reps) * ops.launches_per_apply()
+                gbs = algorithmic_bytes_per_cell(Ps) * parts.ncells / (ms * 1e-3) / 1e9
+                sweep[f"p{Ps}"] = {"cells": ns**3, "dofs": lvs.ndofs, "apply_ms": round(ms, 5), "achieved": round(gbs, 1),
+                                   "frac": round(gbs / HBM_PEAK_GBS, 4)}
+                del ops, us, ys, lays, lvs, parts
+                torch.cuda.empty_cache()
+            out["degree_sweep"] = {"note": "operator apply only, model storedG, GB/s of 8000 (BASELINE config 4); not `value`",
+                                   **sweep}
+
+    with extra(out, "degree_sweep"):
+        _degree_sweep()
 
     # ---- CPU baseline: the C/OpenMP port of the same lean V-cycle on the host cores (rank 0, N = 1) ----
-    if world == 1 and not args.no_cpu:
-        from oracle import c_oracle as co
+    def _cpu_baseline():
+        if world == 1 and not args.no_cpu:
+            from oracle import c_oracle as co
 
-        t0 = time.time()
-        part = H.part
-        cl = [co.CLevel(p, 2.0, part.level(p).dofmap, part.xgeom, part.geom_dofmap, part.level(p).bc_marker)
-              for p in orders]
-        ci = [co.CInterp(cl[i], cl[i + 1]) for i in range(len(orders) - 1)]
-        cm = co.CMultigrid(cl, ci, [e[1] for e in H.eig_ranges], args.cheb)
-        bh = b.data_copy()
-        xc = np.zeros_like(bh)
-        cm.apply(bh, xc)  # first cycle from x0 = 0: also the parity check below
-        ncpu = 4
-        tc = time.perf_counter()
-        for _ in range(ncpu):
-            cm.apply(bh, xc)
-        cpu_s = (time.perf_counter() - tc) / ncpu
-        log(f"cpu baseline: setup {time.time() - t0 - cpu_s * ncpu:.1f}s, {cpu_s:.2f}s per V-cycle on "
-            f"{co.num_threads()} threads")
-        # parity in the same run: 1 + ncpu GPU V-cycles from x0 = 0 against the CPU ones
-        xg = H.new_vector()
-        xg.set(0.0)
-        for _ in range(1 + ncpu):
-            H.mg.apply(b, xg)
-        torch.cuda.synchronize()
-        got = xg.data_copy()
-        err = float(np.abs(got - xc).max() / np.abs(xc).max())
-        out["cpu_baseline"] = {"value": fine_dofs_global / cpu_s, "unit": "DoF/s", "cores": co.num_threads(),
-                               "kind": "port",
-                               "sample": f"{ncpu} V-cycles of the same workload ({args.n}^3 hexes, "
-                                         f"{fine_dofs_global} fine dofs), C/OpenMP oracle, after 1 warm-up cycle"}
-        out["parity"] = {f"gpu_vs_cpu_oracle_rel_err_after_{1 + ncpu}_cycles": err, "tolerance": 1e-10}
-        if not err < 1e-10:
-            log(f"PARITY FAILURE: {err}")
-            out["parity"]["failed"] = True
+            t0 = time.time()
+            part = H.part
+            cl = [co.CLevel(p, 2.0, part.level(p).dofmap, part.xgeom, part.geom_dofmap, part.level(p).bc_marker)
+                  for p in orders]
+            ci = [co.CInterp(cl[i], cl[i + 1]) for i in range(len(orders) - 1)]
+            cm = co.CMultigrid(cl, ci, [e[1] for e in H.eig_ranges], args.cheb)
+            bh = b.data_copy()
+            xc = np.zeros_like(bh)
+            cm.apply(bh, xc)  # first cycle from x0 = 0: also the parity check below
+            ncpu = 4
+            tc = time.perf_counter()
+            for _ in range(ncpu):
+                cm.apply(bh, xc)
+            cpu_s = (time.perf_counter() - tc) / ncpu
+            log(f"cpu baseline: setup {time.time() - t0 - cpu_s * ncpu:.1f}s, {cpu_s:.2f}s per V-cycle on "
+                f"{co.num_threads()} threads")
+            # parity in the same run: 1 + ncpu GPU V-cycles from x0 = 0 against the CPU ones
+            xg = H.new_vector()
+            xg.set(0.0)
+            for _ in range(1 + ncpu):
+                H.mg.apply(b, xg)
+            torch.cuda.synchronize()
+            got = xg.data_copy()
+            err = float(np.abs(got - xc).max() / np.abs(xc).max())
+            out["cpu_baseline"] = {"value": fine_dofs_global / cpu_s, "unit": "DoF/s", "cores": co.num_threads(),
+                                   "kind": "port",
+                                   "sample": f"{ncpu} V-cycles of the same workload ({args.n}^3 hexes, "
+                                             f"{fine_dofs_global} fine dofs), C/OpenMP oracle, after 1 warm-up cycle"}
+            out["parity"] = {f"gpu_vs_cpu_oracle_rel_err_after_{1 + ncpu}_cycles": err, "tolerance": 1e-10}
+            if not err < 1e-10:
+                log(f"PARITY FAILURE: {err}")
+                out["parity"]["failed"] = True
+
+    with extra(out, "cpu_baseline"):
+        _cpu_baseline()
 
     if rank == 0:
         print(json.dumps(out), flush=True)
