@@ -59,9 +59,8 @@ int main(int argc, char** argv)
     device_array<std::int32_t> dofmap(V.dofmap), xdofmap(mesh.geom_dofmap);
     device_array<double> xgeom(mesh.xgeom);
     device_array<std::int8_t> bc(V.bc_marker);
-    std::vector<int> lcells(mesh.ncells()), bcells; // one rank: every cell is local (src/mesh.hpp:105-143)
-    for (int c = 0; c < mesh.ncells(); ++c)
-      lcells[c] = c;
+    // one rank: no ghost dofs, so every cell comes out local (src/mesh.hpp:105-143)
+    auto [lcells, bcells] = compute_boundary_cells(V.dofmap, mesh.ncells(), mesh.ncells(), nd * nd * nd, V.ndofs);
 
     auto t0 = std::chrono::steady_clock::now();
     acc::MatFreeLaplacian op(degree, kappa.span(), dofmap.span(), xgeom.span(), xdofmap.span(), {}, {}, lcells,

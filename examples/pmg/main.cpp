@@ -19,6 +19,7 @@
 #include <cstring>
 #include <iostream>
 #include <sstream>
+#include <tuple>
 
 using namespace pmg_amd;
 using DeviceVector = acc::Vector;
@@ -70,10 +71,7 @@ int main(int argc, char** argv)
     device_array<double> kappa_d(std::vector<double>(mesh.ncells(), kappa));
     device_array<double> xgeom(mesh.xgeom);
     device_array<std::int32_t> xdofmap(mesh.geom_dofmap);
-    std::vector<int> lcells(mesh.ncells()), bcells;
-    for (int c = 0; c < mesh.ncells(); ++c)
-      lcells[c] = c;
-    std::vector<std::int32_t> lcells32(lcells.begin(), lcells.end()), bcells32;
+    std::vector<int> lcells, bcells; // src/mesh.hpp:105-143; the same split on every level
 
     std::vector<std::shared_ptr<const IndexMap>> maps(L);
     std::vector<device_array<std::int32_t>> dofmaps(L);
@@ -87,6 +85,8 @@ int main(int argc, char** argv)
       check(pmg_gll_table(nd, gll.data(), w.data()));
       examples::FunctionSpace V(mesh, P, gll);
       std::cout << "Level " << i << ": degree " << P << ", " << V.ndofs << " dofs\n";
+      if (i == 0)
+        std::tie(lcells, bcells) = compute_boundary_cells(V.dofmap, mesh.ncells(), mesh.ncells(), nd * nd * nd, V.ndofs);
       maps[i] = std::make_shared<const IndexMap>(V.ndofs, 0);
       dofmaps[i].assign(V.dofmap);
       bc_markers[i].assign(V.bc_marker);
@@ -127,6 +127,7 @@ int main(int argc, char** argv)
       smoothers[i]->set_max_iterations(cheb_its);
     }
 
+    std::vector<std::int32_t> lcells32(lcells.begin(), lcells.end()), bcells32(bcells.begin(), bcells.end());
     std::vector<std::shared_ptr<Interpolator>> interpolators(L - 1);
     for (std::size_t i = 0; i + 1 < L; ++i)
       interpolators[i] = std::make_shared<Interpolator>(orders[i], orders[i + 1], dofmaps[i].span(),

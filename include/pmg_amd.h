@@ -94,6 +94,11 @@ int pmg_layout_create(pmg_layout* out, int32_t size_local, int32_t num_ghosts, i
 int pmg_layout_destroy(pmg_layout l);
 int32_t pmg_layout_size_local(pmg_layout l);
 int32_t pmg_layout_num_ghosts(pmg_layout l);
+/* Optional: the maximum over all ranks of n host doubles, in place (the reference's
+ * MPI_Allreduce(MPI_MAX) of norm(linf), src/vector.hpp:383-385); `user` is the pointer given
+ * to pmg_layout_create.  Without it pmg_vec_norm(linf) fails on a layout that has an
+ * allreduce_sum callback (several ranks), because a sum cannot stand in for a maximum. */
+int pmg_layout_set_allreduce_max(pmg_layout l, pmg_allreduce_fn allreduce_max);
 
 /* Vector::scatter_fwd_begin / scatter_fwd_end (src/vector.hpp:186-238): owner ->
  * ghost update of x; pack/unpack run on `stream` without host synchronisation. */

@@ -115,13 +115,15 @@ class IndexMap
 public:
   IndexMap(std::int32_t size_local, std::int32_t num_ghosts, std::span<const std::int32_t> send_indices = {},
            std::span<const std::int32_t> recv_indices = {}, pmg_exchange_fn exchange = nullptr,
-           pmg_allreduce_fn allreduce_sum = nullptr, void* user = nullptr)
+           pmg_allreduce_fn allreduce_sum = nullptr, void* user = nullptr, pmg_allreduce_fn allreduce_max = nullptr)
       : _size_local(size_local), _num_ghosts(num_ghosts), _send_idx(send_indices), _recv_idx(recv_indices),
         _send(send_indices.size()), _recv(recv_indices.size())
   {
     check(pmg_layout_create(&_layout, size_local, num_ghosts, (std::int32_t)send_indices.size(), _send_idx.data(),
                             _send.data(), (std::int32_t)recv_indices.size(), _recv_idx.data(), _recv.data(),
                             exchange, allreduce_sum, user));
+    if (allreduce_max)
+      check(pmg_layout_set_allreduce_max(_layout, allreduce_max));
   }
   IndexMap(const IndexMap&) = delete;
   IndexMap& operator=(const IndexMap&) = delete;
@@ -140,6 +142,27 @@ private:
   device_array<double> _send, _recv;
   pmg_layout _layout = nullptr;
 };
+
+/// compute_boundary_cells (src/mesh.hpp:105-143) on flattened inputs: cells that touch
+/// no ghost dof ("local": they can run while the halo is in flight) and cells that do,
+/// plus every ghost cell ("boundary").  `dofmap` is a host array [ncells][N]; the first
+/// ncells_owned cells are owned, the rest are ghost cells.
+inline std::pair<std::vector<int>, std::vector<int>>
+compute_boundary_cells(std::span<const std::int32_t> dofmap, std::int32_t ncells_owned, std::int32_t ncells, int N,
+                       std::int32_t size_local)
+{
+  if ((std::size_t)ncells * N != dofmap.size() || ncells_owned > ncells)
+    throw std::runtime_error("compute_boundary_cells: dofmap size does not match the cell counts");
+  std::vector<int> local_cells, boundary_cells;
+  for (std::int32_t c = 0; c < ncells; ++c)
+  {
+    bool mark = c >= ncells_owned;
+    for (int k = 0; !mark && k < N; ++k)
+      mark = dofmap[(std::size_t)c * N + k] >= size_local;
+    (mark ? boundary_cells : local_cells).push_back(c);
+  }
+  return {std::move(local_cells), std::move(boundary_cells)};
+}
 
 namespace acc
 {

@@ -40,6 +40,7 @@ _SIGS = {
     "pmg_layout_destroy": (C.c_int, [vp]),
     "pmg_layout_size_local": (C.c_int32, [vp]),
     "pmg_layout_num_ghosts": (C.c_int32, [vp]),
+    "pmg_layout_set_allreduce_max": (C.c_int, [vp, ALLREDUCE_FN]),
     "pmg_scatter_fwd_begin": (C.c_int, [vp, vp, vp]),
     "pmg_scatter_fwd_end": (C.c_int, [vp, vp, vp]),
     "pmg_scatter_rev_begin": (C.c_int, [vp, vp, vp]),

@@ -88,6 +88,7 @@ struct pmg_layout_s
   double* recv_buf = nullptr;
   pmg_exchange_fn exchange = nullptr;
   pmg_allreduce_fn allreduce = nullptr;
+  pmg_allreduce_fn allreduce_max = nullptr;
   void* user = nullptr;
   // reduction scratch (owned)
   double* d_partials = nullptr; // [2 * RED_BLOCKS]

@@ -542,6 +542,12 @@ extern "C" int pmg_layout_destroy(pmg_layout l)
 
 extern "C" int32_t pmg_layout_size_local(pmg_layout l) { return l ? l->size_local : -1; }
 extern "C" int32_t pmg_layout_num_ghosts(pmg_layout l) { return l ? l->num_ghosts : -1; }
+extern "C" int pmg_layout_set_allreduce_max(pmg_layout l, pmg_allreduce_fn allreduce_max)
+{
+  PMG_REQUIRE(l, "pmg_layout_set_allreduce_max: NULL layout");
+  l->allreduce_max = allreduce_max;
+  return PMG_OK;
+}
 
 // src/vector.hpp:186-207
 extern "C" int pmg_scatter_fwd_begin(pmg_layout l, const double* x, pmg_stream stream)
@@ -671,8 +677,8 @@ extern "C" int pmg_vec_norm(pmg_layout l, const double* a, int norm_type, double
     return PMG_OK;
   }
   PMG_REQUIRE(norm_type == 1, "Norm type not supported"); // src/vector.hpp:388
-  PMG_REQUIRE(!l->allreduce, "pmg_vec_norm: linf needs a max-reduction, not available through "
-                             "the sum-only allreduce callback");
+  PMG_REQUIRE(!l->allreduce || l->allreduce_max,
+              "pmg_vec_norm: linf over several ranks needs pmg_layout_set_allreduce_max");
   int nb = ew_blocks(l->size_local);
   if (nb > RED_BLOCKS)
     nb = RED_BLOCKS;
@@ -682,6 +688,9 @@ extern "C" int pmg_vec_norm(pmg_layout l, const double* a, int norm_type, double
   PMG_HIP(hipMemcpyAsync(l->h_result, l->d_partials + RED_BLOCKS, sizeof(double),
                          hipMemcpyDeviceToHost, S(stream)));
   PMG_HIP(hipStreamSynchronize(S(stream)));
-  *result = l->h_result[0];
+  double v = l->h_result[0];
+  if (l->allreduce_max)
+    PMG_REQUIRE(l->allreduce_max(l->user, &v, 1) == 0, "pmg_vec_norm: the allreduce_max callback failed");
+  *result = v;
   return PMG_OK;
 }

@@ -86,6 +86,9 @@ class Layout:
              ptr(self.send_buffer), n_recv, ptr(self.recv_indices), ptr(self.recv_buffer), self._cb_exchange,
              self._cb_allreduce, vp(0))
         self._handle = h
+        if self.distributed:
+            self._cb_allreduce_max = _lib.ALLREDUCE_FN(lambda user, values, n: self._allreduce(user, values, n, "max"))
+            call("pmg_layout_set_allreduce_max", h, self._cb_allreduce_max)
         _REGISTRY[id(self)] = self
 
     # ---- per-rank split sizes for all_to_all_single ----
@@ -145,7 +148,7 @@ class Layout:
             dst.copy_(host_out)
         return 0
 
-    def _allreduce(self, user, values, n):
+    def _allreduce(self, user, values, n, op="sum"):
         try:
             import torch
 
@@ -154,7 +157,7 @@ class Layout:
             t = torch.from_numpy(host.copy())
             if dist.get_backend(self.group) == "nccl":
                 t = t.to(self.device)
-            dist.all_reduce(t, group=self.group)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=self.group)
             host[:] = t.cpu().numpy()
             return 0
         except Exception:

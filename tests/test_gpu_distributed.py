@@ -57,6 +57,7 @@ def _worker(rank, world, port, n, dims, orders, q):
             assert np.array_equal(x.data_copy(), ug[lv.local_to_global])
             # distributed reductions
             assert abs(pm.inner_product(x, x) - ug @ ug) < 1e-10 * (ug @ ug)
+            assert pm.norm(x, "linf") == np.abs(ug).max()  # max-reduction over the ranks (src/vector.hpp:383-385)
         out["apply_err"] = errs
         # V-cycles against the single-domain oracle with the same smoother bounds
         mesh, ops, sm, it, mg, b, eigs = po.build_hierarchy(n, orders, cheb_its=k, warp=warp)
@@ -147,6 +148,7 @@ def _rccl_worker(port, q):
                 np.add.at(ref, send, a[send])
                 out[name + "_rev"] = float(np.abs(x.data_copy()[:n] - ref).max())
                 out[name + "_dot"] = abs(pm.inner_product(x, x) - ref @ ref) / (ref @ ref)
+                out[name + "_linf"] = bool(pm.norm(x, "linf") == np.abs(x.data_copy()[:n]).max())
         # a hierarchy under an initialised RCCL group still runs (single brick: no exchange partners)
         H = pm.PoissonHierarchy(4, (1, 2), cheb_its=2)
         v = H.new_vector()
@@ -172,5 +174,5 @@ def test_rccl_branch_single_rank(built):
     assert p.exitcode == 0
     for s in ("default", "side"):
         assert out[s + "_fwd"]
-        assert out[s + "_rev"] < 1e-14 and out[s + "_dot"] < 1e-13
+        assert out[s + "_rev"] < 1e-14 and out[s + "_dot"] < 1e-13 and out[s + "_linf"]
     assert np.isfinite(out["rnorm"]) and out["rnorm"] > 0

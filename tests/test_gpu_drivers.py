@@ -86,3 +86,10 @@ def test_driver_errors(built):
     path = os.path.join(BIN, "mat_free_main")
     r = subprocess.run([path, "--degree", "9"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "Unsupported degree" in r.stderr  # src/laplacian.hpp:346
+
+
+def test_cpp_adapter_selftest(built):
+    """Vector algebra, halo scatter through a C++ exchange callback, compute_boundary_cells and
+    the reference's error behaviour, checked inside the C++ program itself."""
+    out = run("selftest_main")
+    assert "adapter selftest passed" in out
