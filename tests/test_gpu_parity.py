@@ -377,3 +377,61 @@ def test_affine_geometry_mode(pm, P):
     assert not op2.is_affine()
     with pytest.raises(RuntimeError, match="non-affine"):
         op2.set_geometry_mode("affine")
+
+
+@pytest.mark.parametrize("P,pc", [(1, None), (2, 1), (3, None), (4, 2), (6, 3), (8, 4)])
+def test_irregular_numbering(pm, P, pc):
+    """What a dolfinx mesh looks like to the library: cells in arbitrary order, dofs
+    renumbered arbitrarily, vertices off any tensor grid (so the patch builder takes its
+    Morton-chunk path and has to close patches early).  Apply, inverse diagonal and the
+    patched transfers against the oracle on the very same arrays."""
+    from oracle import pmg_oracle as po
+
+    rng = np.random.default_rng(1000 + P)
+    n = (5, 4, 6) if P <= 4 else (3, 2, 3)
+    part = pm.BoxPartition(n, warp=twist)
+    lv = part.level(P)
+    ncells, ndofs = part.ncells, lv.ndofs
+    # jitter the interior vertices (cells stay valid hexes: the jitter is small against h)
+    x = part.xgeom.copy()
+    h = 1.0 / max(n)
+    inner = np.all((x > 1e-9) & (x < 1 + 0.3), axis=1)
+    x[inner] += 0.08 * h * rng.uniform(-1, 1, (int(inner.sum()), 3))
+    cperm = rng.permutation(ncells)
+    dperm = rng.permutation(ndofs)  # old dof -> new dof
+    dofmap = dperm[lv.dofmap[cperm]].astype(np.int32)
+    gdm = part.geom_dofmap[cperm]
+    bc = np.zeros(ndofs, dtype=np.int8)
+    bc[dperm] = lv.bc_marker
+    kappa = rng.uniform(0.5, 3.0, ncells)
+    # an arbitrary split into the two cell lists (the library must not care which is which)
+    mask = rng.uniform(size=ncells) < 0.7
+    lcells, bcells = np.nonzero(mask)[0].astype(np.int32), np.nonzero(~mask)[0].astype(np.int32)
+    layout = pm.Layout(ndofs)
+    op = pm.MatFreeLaplacian(P, kappa, dofmap, x, gdm, lcells, bcells, bc, layout)
+    A = po.Laplacian(P, kappa, dofmap, x, gdm, bc)
+    assert not op.is_affine()
+    u = rng.standard_normal(ndofs)
+    vx, vy = _vec(pm, layout, u), pm.Vector(layout)
+    vy.set(9.0)
+    op(vx, vy)
+    assert _relerr(vy.data_copy(), A.apply(u)) < 1e-12
+    op.compute_diag_inverse()
+    d = pm.Vector(layout)
+    op.get_diag_inverse(d)
+    assert _relerr(d.data_copy(), A.diag_inverse()) < 1e-12
+    if pc is None:
+        return
+    lvc = part.level(pc)
+    cdperm = rng.permutation(lvc.ndofs)
+    dmc = cdperm[lvc.dofmap[cperm]].astype(np.int32)
+    Lc = pm.Layout(lvc.ndofs)
+    ip = pm.Interpolator(pc, P, dmc, dofmap, lcells, bcells, Lc, layout, fine_operator=op)
+    oi = po.Interpolator(pc, P, dmc, dofmap, lvc.ndofs, ndofs)
+    uc = rng.standard_normal(lvc.ndofs)
+    vc, vf = _vec(pm, Lc, uc), _vec(pm, layout, u)
+    ip.interpolate_add(vc, vf)
+    assert _relerr(vf.data_copy(), u + oi.interpolate(uc)) < 1e-13
+    vc2 = pm.Vector(Lc)
+    ip.reverse_interpolate(vx, vc2)
+    assert _relerr(vc2.data_copy(), oi.reverse_interpolate(u)) < 1e-12
