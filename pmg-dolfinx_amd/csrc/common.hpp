@@ -112,6 +112,8 @@ void launch_cheb_init(int n, double* r, double* z, const double* b, const double
 void launch_cheb_step(int n, double* x, double* r, double* z, const double* q, const double* dinv,
                       double c1, double c2, hipStream_t s);
 void launch_add(int n, double* x, const double* z, hipStream_t s);
+void launch_cheb_last(int n, double* x, double* r, const double* z, const double* q, bool assign,
+                      hipStream_t s);
 void launch_mask_bc(int n, double* b, const int8_t* bc, hipStream_t s);
 // CG fused passes (src/cg.hpp:160-211)
 void launch_cg_update(int n, double* x, double* r, double* y, const double* p, const double* dinv,

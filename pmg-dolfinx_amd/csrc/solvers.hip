@@ -102,6 +102,11 @@ int cheb_solve(pmg_chebyshev sm, pmg_laplacian A, double* x, const double* b, bo
       break;
     }
     PMG_TRY(laplacian_apply(A, sm->z, sm->q, s)); // :76
+    if (last) // need_r: the new z would not be used, only x and r are (:73,77)
+    {
+      launch_cheb_last(n, x, sm->r, sm->z, sm->q, x_zero && i == 1, s);
+      break;
+    }
     const double c1 = (2.0 * i - 1.0) / (2.0 * i + 3.0);
     const double c2 = (8.0 * i + 4.0) / (2.0 * i + 3.0) / lmax;
     if (x_zero && i == 1)

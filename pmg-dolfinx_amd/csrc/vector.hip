@@ -256,6 +256,27 @@ struct ChebFirstF
   }
 };
 template <bool NT>
+struct ChebLastF
+{ // last step when only x and the residual are wanted:  x (+)= z ; r -= q
+  double* x;
+  double* r;
+  const double* z;
+  const double* q;
+  int assign; // x = z (first step from x == 0) instead of x += z
+  __device__ void pair(int i) const
+  {
+    double2 vr = ld2<NT>(r, i), vz = ld2<NT>(z, i), vq = ld2<NT>(q, i);
+    double2 vx = assign ? make_double2(0.0, 0.0) : ld2<NT>(x, i);
+    D2(x)[i] = make_double2(vx.x + vz.x, vx.y + vz.y); // x is gathered next (prolongation)
+    st2<NT>(r, i, make_double2(vr.x - vq.x, vr.y - vq.y));
+  }
+  __device__ void one(int i) const
+  {
+    x[i] = (assign ? 0.0 : x[i]) + z[i];
+    r[i] -= q[i];
+  }
+};
+template <bool NT>
 struct AddF
 { // x += z
   double* x;
@@ -435,6 +456,15 @@ void launch_cheb_first(int n, double* x, double* r, double* z, const double* q, 
     ew_launch(n, v, ChebFirstF<true>{x, r, z, q, dinv, c1, c2}, s);
   else
     ew_launch(n, v, ChebFirstF<false>{x, r, z, q, dinv, c1, c2}, s);
+}
+void launch_cheb_last(int n, double* x, double* r, const double* z, const double* q, bool assign,
+                      hipStream_t s)
+{
+  bool v = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(q);
+  if (streams(n))
+    ew_launch(n, v, ChebLastF<true>{x, r, z, q, assign ? 1 : 0}, s);
+  else
+    ew_launch(n, v, ChebLastF<false>{x, r, z, q, assign ? 1 : 0}, s);
 }
 void launch_add(int n, double* x, const double* z, hipStream_t s)
 {
