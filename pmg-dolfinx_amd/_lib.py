@@ -129,6 +129,11 @@ def lib():
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root. "
                 "There is no CPU fallback."
             )
+        # torch bundles a HIP runtime with the same soname as the system's (libamdhip64.so.7); the one
+        # loaded first serves the whole process.  It has to be torch's: with the system runtime
+        # loaded first torch's own libraries no longer find the device.  So torch goes first.
+        import torch  # noqa: F401
+
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             f = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
