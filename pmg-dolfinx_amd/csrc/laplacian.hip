@@ -70,6 +70,7 @@ struct pmg_laplacian_s
   long long npdofs = 0;
   int max_m = 0;
   int n_launch_l = 0;
+  int n_plain = 0;
   bool needs_zero = false; // some local dof belongs to no listed cell
   double* diag_inv = nullptr; // [size_local + num_ghosts]
   bool have_diag = false;
@@ -897,7 +898,7 @@ int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, h
   for (int l = l0; l < l1; ++l)
   {
     const int first = op->launch_first[l], count = op->launch_count[l];
-    const int atomic_out = (l >= op->n_launch_l) ? 1 : 0; // the merged boundary launch
+    const int atomic_out = (l >= op->n_plain) ? 1 : 0; // merged launches add with atomics
     switch (op->P)
     {
     case 1:
@@ -979,9 +980,12 @@ int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s)
 {
   pmg_layout l = op->layout;
   const int nl = (int)op->launch_first.size();
-  if (op->needs_zero || nl == 0)
-    PMG_HIP(hipMemsetAsync(out, 0, sizeof(double) * l->total(), s)); // :466 (else: first-writer stores)
-  if (op->n_bzero > 0 && !(op->needs_zero || nl == 0))
+  // :466 -- but only where needed: dofs no patch touches, or (most of the vector) dofs whose
+  // first writer adds with atomics; everything else is stored by its first writer
+  const bool zero_all = op->needs_zero || nl == 0 || 2LL * op->n_bzero > l->total();
+  if (zero_all)
+    PMG_HIP(hipMemsetAsync(out, 0, sizeof(double) * l->total(), s));
+  if (op->n_bzero > 0 && !zero_all)
     zero_list_kernel<<<(op->n_bzero + 255) / 256 > 1024 ? 1024 : (op->n_bzero + 255) / 256, 256, 0, s>>>(
         op->n_bzero, op->bzero, out);
   PMG_TRY(pmg_scatter_fwd_begin(l, in, (pmg_stream)s));          // :378
@@ -1159,6 +1163,7 @@ extern "C" int pmg_laplacian_create_with_tables(
   op->launch_first = plan.launch_first;
   op->launch_count = plan.launch_count;
   op->n_launch_l = plan.n_launch_l;
+  op->n_plain = plan.n_plain;
   PMG_TRY(upload(&op->pcell, plan.pcell.data(), plan.pcell.size(), s));
   PMG_TRY(upload(&op->pncell, plan.pncell.data(), plan.pncell.size(), s));
   op->n_bzero = (int32_t)plan.bzero.size();

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <numeric>
 
@@ -328,17 +329,49 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
     plan.lmap_id[i] = it->second;
   }
   plan.nuniq = (int)uniq.size();
-  // merge the boundary colours into one (atomic) launch
-  if (nlaunch > plan.n_launch_l)
+  // Launch list.  The boundary colours are always merged into one atomic launch (a thin
+  // shell: many small launches otherwise).  The interior colours are merged as well when
+  // the level is small: eight launches that cannot fill the GPU are launch- and ramp-bound,
+  // one launch that adds with atomics is not, as long as the atomics stay few.  Measured
+  // (stiffness kernel alone, colours -> merged): P=1 16^3 27 -> 4 us, 64^3 43 -> 23 us;
+  // P=2 32^3 79 -> 13, 48^3 90 -> 47, 64^3 (2.8 M patch dofs) 110 -> 116; P=3 32^3 59 -> 31,
+  // 48^3 100 -> 96; P=4 24^3 102 -> 29, 32^3 111 -> 66, 40^3 (5.3 M) 150 -> 126, 48^3 (9.2 M)
+  // 206 -> 219, 64^3 427 -> 570; P=6 24^3 141 -> 94; P=8 16^3 174 -> 73.  Hence the
+  // thresholds below, in patch dofs (= atomically added values) of the interior list.
   {
-    const int nl = plan.n_launch_l;
-    const int32_t bfirst = plan.launch_first[nl];
-    plan.launch_first.resize(nl + 1);
-    plan.launch_count.resize(nl + 1);
-    plan.launch_first[nl] = bfirst;
-    plan.launch_count[nl] = np - bfirst;
+    const int nl = ncolours[0];
+    const int32_t bfirst = nl < nlaunch ? plan.launch_first[nl] : np;
+    const long long interior_pdofs = plan.poff[bfirst];
+    long long merge_below = (P <= 2 ? 2 : 6) << 20;
+    if (const char* e = getenv("PMG_MERGE_BELOW"))
+      merge_below = atoll(e);
+    const bool merge_interior = nl > 1 && interior_pdofs <= merge_below;
+    std::vector<int32_t> lf, lc;
+    if (merge_interior)
+    {
+      lf.push_back(0);
+      lc.push_back(bfirst);
+      plan.n_plain = 0;
+      plan.n_launch_l = 1;
+    }
+    else
+    {
+      lf.assign(plan.launch_first.begin(), plan.launch_first.begin() + nl);
+      lc.assign(plan.launch_count.begin(), plan.launch_count.begin() + nl);
+      plan.n_plain = nl;
+      plan.n_launch_l = nl;
+    }
+    if (bfirst < np)
+    {
+      lf.push_back(bfirst);
+      lc.push_back(np - bfirst);
+    }
+    plan.launch_first = lf;
+    plan.launch_count = lc;
+    // dofs whose first writer is an atomic launch must be zero beforehand
+    const int first_atomic_colour = merge_interior ? 0 : nl;
     for (int32_t d = 0; d < ndofs; ++d)
-      if (first[d] != INT32_MAX && first[d] >= nl && !bc[d])
+      if (first[d] != INT32_MAX && first[d] >= first_atomic_colour && !bc[d])
         plan.bzero.push_back(d);
   }
   return PMG_OK;

@@ -108,12 +108,14 @@ struct PatchPlan
   // launches: contiguous patch ranges, in stream order; first n_launch_l belong to lcells
   std::vector<int32_t> launch_first, launch_count;
   int n_launch_l = 0;
+  int n_plain = 0; // the first n_plain launches store (colours); the rest add with atomics
   int max_M = 0;
   // The boundary cell list is a thin shell: its colours would be many small
   // launches.  They are issued as ONE launch whose patches add their sums to y
-  // with atomics (few, in long runs); bzero lists the dofs no interior patch
-  // writes, which must be zero before that launch.  The PD_ACC flags still name a
-  // unique first patch per dof (the transfers rely on that).
+  // with atomics (few, in long runs); so are the interior colours of a small level.
+  // bzero lists the dofs whose first writer is such a launch, which must be zero
+  // beforehand.  The PD_ACC flags still name a unique first patch per dof (the
+  // transfers and the Dirichlet rows rely on that).
   std::vector<int32_t> bzero;
 };
 
