@@ -8,8 +8,10 @@
  * Citations are relative to the reference tree Wells-Group/pmg-dolfinx @
  * 2024_08_07.  The reference's own implementation of this path cannot be built
  * here (every header needs dolfinx/basix), so this is a port of
- * the algorithm, pinned by the analytic KATs in tests/ and cross-checked
- * against the numpy restatement.
+ * the algorithm.  Apart from TQLI (the reference's python_tests/tqli.py fixture,
+ * tests/golden) the reference holds no golden vectors for this path -- parity
+ * unpinned by the reference itself; it is pinned by the analytic KATs in tests/
+ * and cross-checked against the numpy restatement.
  *
  * Layouts follow the reference: dofmap [ncells][N] int32 with local index
  * t = a*nd^2 + b*nd + c (src/laplacian.hpp:173); G [ncells][N][6]

@@ -27,8 +27,10 @@ Lagrange basis on the GLL nodes (``gll_warped`` variant = GLL nodes), trilinear
 coordinate element, point-evaluation interpolation operator.
 
 Parity pinning: the only executable fixture in the reference for this path is
-``python_tests/tqli.py`` (golden eigenvalues, see ``tests/golden``); everything
-else is pinned by the analytic known-answer tests listed in ``SURVEY.md`` §8(c)
+``python_tests/tqli.py`` (golden eigenvalues, see ``tests/golden``) -- TQLI is
+pinned by it; for everything else the reference holds no golden vector or
+known-answer test, i.e. PARITY UNPINNED by the reference itself: those parts are
+pinned by the analytic known-answer tests listed in ``SURVEY.md`` §8(c)
 (7-point stencil at P=1, null space, exact energy of linear fields, symmetry,
 mat-free == assembled CSR, polynomial reproduction by prolongation, ...).
 
