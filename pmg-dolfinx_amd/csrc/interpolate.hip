@@ -216,10 +216,38 @@ __global__ void prolong_patch_kernel(TransferArgs A, const double* __restrict__ 
   double* t2 = t1 + n1;
   const uint16_t* cl = A.clmaps + (size_t)A.clmap_id[p] * A.K * Nc;
   const uint16_t* fl = A.lmaps + (size_t)A.lmap_id[p] * A.K * Nf;
+  // the (cell, local dof) -> patch position tables of the NEXT cell are fetched while the
+  // current one is computed, so the cell loop itself touches only LDS
+  constexpr int FP = (Nf + 63) / 64, CP = (Nc + 63) / 64;
+  int fcur[FP], ccur[CP], fnxt[FP], cnxt[CP];
+  auto fetch = [&](int slot, int* fi, int* ci) {
+#pragma unroll
+    for (int j = 0; j < CP; ++j)
+    {
+      const int o = lane + 64 * j;
+      ci[j] = cl[(size_t)slot * Nc + (o < Nc ? o : Nc - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < FP; ++j)
+    {
+      const int o = lane + 64 * j, oc = o < Nf ? o : Nf - 1;
+      const int a = oc / (ndf * ndf), r = oc - a * ndf * ndf, b = r / ndf, c = r - b * ndf;
+      fi[j] = fl[(size_t)slot * Nf + ftab(A.column, ndf, a, b, c)];
+    }
+  };
+  if (wave < nc)
+    fetch(wave, fcur, ccur);
   for (int slot = wave; slot < nc; slot += nw)
   {
-    for (int o = lane; o < Nc; o += 64)
-      uc[o] = sc[cl[(size_t)slot * Nc + o]];
+    if (slot + nw < nc)
+      fetch(slot + nw, fnxt, cnxt);
+#pragma unroll
+    for (int j = 0; j < CP; ++j)
+    {
+      const int o = lane + 64 * j;
+      if (o < Nc)
+        uc[o] = sc[ccur[j]];
+    }
     tfence();
     for (int o = lane; o < n1; o += 64) // (a, j, k): sum over i
     {
@@ -241,16 +269,27 @@ __global__ void prolong_patch_kernel(TransferArgs A, const double* __restrict__ 
       t2[o] = v;
     }
     tfence();
-    for (int o = lane; o < Nf; o += 64) // (a, b, c): sum over k
+#pragma unroll
+    for (int jj = 0; jj < FP; ++jj) // (a, b, c): sum over k
     {
-      const int a = o / (ndf * ndf), r = o - a * ndf * ndf, b = r / ndf, c = r - b * ndf;
-      double v = 0.0;
-      #pragma unroll
-      for (int k = 0; k < ndc; ++k)
-        v += sM[c * ndc + k] * t2[(a * ndf + b) * ndc + k];
-      sf[fl[(size_t)slot * Nf + ftab(A.column, ndf, a, b, c)]] = v; // shared dofs: identical values
+      const int o = lane + 64 * jj;
+      if (o < Nf)
+      {
+        const int a = o / (ndf * ndf), r = o - a * ndf * ndf, b = r / ndf, c = r - b * ndf;
+        double v = 0.0;
+        #pragma unroll
+        for (int k = 0; k < ndc; ++k)
+          v += sM[c * ndc + k] * t2[(a * ndf + b) * ndc + k];
+        sf[fcur[jj]] = v; // shared dofs: identical values
+      }
     }
     tfence();
+#pragma unroll
+    for (int j = 0; j < CP; ++j)
+      ccur[j] = cnxt[j];
+#pragma unroll
+    for (int j = 0; j < FP; ++j)
+      fcur[j] = fnxt[j];
   }
   tbarrier();
   for (int i0 = t; i0 < Mf; i0 += 4 * blockDim.x)
@@ -331,12 +370,35 @@ __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__
   double* t1 = t2 + n2;
   const uint16_t* cl = A.clmaps + (size_t)A.clmap_id[p] * A.K * Nc;
   const uint16_t* fl = A.lmaps + (size_t)A.lmap_id[p] * A.K * Nf;
+  constexpr int FP = (Nf + 63) / 64, CP = (Nc + 63) / 64;
+  int fcur[FP], ccur[CP], fnxt[FP], cnxt[CP]; // position tables, fetched one cell ahead (see prolong_patch_kernel)
+  auto fetch = [&](int slot, int* fi, int* ci) {
+#pragma unroll
+    for (int j = 0; j < CP; ++j)
+    {
+      const int o = lane + 64 * j;
+      ci[j] = cl[(size_t)slot * Nc + (o < Nc ? o : Nc - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < FP; ++j)
+    {
+      const int o = lane + 64 * j, oc = o < Nf ? o : Nf - 1;
+      const int a = oc / (ndf * ndf), r = oc - a * ndf * ndf, b = r / ndf, c = r - b * ndf;
+      fi[j] = fl[(size_t)slot * Nf + ftab(A.column, ndf, a, b, c)];
+    }
+  };
+  if (wave < nc)
+    fetch(wave, fcur, ccur);
   for (int slot = wave; slot < nc; slot += nw)
   {
-    for (int o = lane; o < Nf; o += 64)
+    if (slot + nw < nc)
+      fetch(slot + nw, fnxt, cnxt);
+#pragma unroll
+    for (int j = 0; j < FP; ++j)
     {
-      const int a = o / (ndf * ndf), r = o - a * ndf * ndf, b = r / ndf, c = r - b * ndf;
-      w[o] = sf[fl[(size_t)slot * Nf + ftab(A.column, ndf, a, b, c)]];
+      const int o = lane + 64 * j;
+      if (o < Nf)
+        w[o] = sf[fcur[j]];
     }
     tfence();
     for (int o = lane; o < n2; o += 64) // (a, b, k): sum over c
@@ -359,16 +421,27 @@ __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__
       t1[o] = v;
     }
     tfence();
-    for (int o = lane; o < Nc; o += 64) // (i, j, k): sum over a
+#pragma unroll
+    for (int jj = 0; jj < CP; ++jj) // (i, j, k): sum over a
     {
-      const int i = o / (ndc * ndc), jk = o - i * ndc * ndc;
-      double v = 0.0;
-      #pragma unroll
-      for (int a = 0; a < ndf; ++a)
-        v += sM[a * ndc + i] * t1[a * ndc * ndc + jk];
-      atomicAdd(&sc[cl[(size_t)slot * Nc + o]], v); // in LDS
+      const int o = lane + 64 * jj;
+      if (o < Nc)
+      {
+        const int i = o / (ndc * ndc), jk = o - i * ndc * ndc;
+        double v = 0.0;
+        #pragma unroll
+        for (int a = 0; a < ndf; ++a)
+          v += sM[a * ndc + i] * t1[a * ndc * ndc + jk];
+        atomicAdd(&sc[ccur[jj]], v); // in LDS
+      }
     }
     tfence();
+#pragma unroll
+    for (int j = 0; j < CP; ++j)
+      ccur[j] = cnxt[j];
+#pragma unroll
+    for (int j = 0; j < FP; ++j)
+      fcur[j] = fnxt[j];
   }
   tbarrier();
   if (atomic_out) // single launch over all patches, coarse zero-filled beforehand
