@@ -29,7 +29,7 @@ int main(int argc, char** argv)
   int n = 64, cheb_its = 3, cycles = 10;
   std::size_t ndofs = 0;
   std::vector<int> orders = {1, 2, 4};
-  bool pcg = false;
+  bool pcg = false, coarse_cg = false;
   for (int i = 1; i < argc; ++i)
   {
     auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
@@ -50,10 +50,12 @@ int main(int argc, char** argv)
       cycles = std::atoi(next());
     else if (!std::strcmp(argv[i], "--pcg"))
       pcg = true;
+    else if (!std::strcmp(argv[i], "--coarse-cg"))
+      coarse_cg = true;
     else
     {
       std::cout << "usage: pmg [--n cells_per_direction | --ndofs N] [--orders 1,2,4] [--smoother-its K] "
-                   "[--cycles C] [--pcg]\n";
+                   "[--cycles C] [--pcg] [--coarse-cg]\n";
       return !std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h") ? 0 : 2;
     }
   }
@@ -139,6 +141,13 @@ int main(int argc, char** argv)
     pmg.set_solvers(smoothers);
     pmg.set_operators(operators);
     pmg.set_interpolators(interpolators);
+    if (coarse_cg) // the reference's --amg role (:331-335: KSPCG, 60 iterations; here Jacobi-preconditioned)
+    {
+      auto coarse = std::make_shared<acc::CGSolver<DeviceVector>>(maps[0], 1);
+      coarse->set_max_iterations(60);
+      coarse->set_tolerance(1e-5);
+      pmg.set_coarse_solver(coarse);
+    }
 
     DeviceVector x(maps.back(), 1);
     x.set(0.0);

@@ -262,14 +262,21 @@ int pmg_interpolator_reverse_interpolate(pmg_interpolator ip, double* fine, doub
 
 /* ---- V-cycle (acc::MultigridPreconditioner, src/pmg.hpp:16-184) -----------
  * Levels are ordered coarse -> fine like the reference's vectors.  The handle
- * allocates its own work vectors (:35-41).  coarse solve = smoother[0]
- * (:106-109; the PETSc/hypre AMG of src/amg.hpp is out of scope). */
+ * allocates its own work vectors (:35-41).  coarse solve = smoother[0] unless
+ * pmg_multigrid_set_coarse_solver is used (:106-109). */
 int pmg_multigrid_create(pmg_multigrid* out, int nlevels, const pmg_layout* layouts,
                          const int8_t* bc_marker_coarsest);
 int pmg_multigrid_destroy(pmg_multigrid mg);
 int pmg_multigrid_set_operators(pmg_multigrid mg, const pmg_laplacian* ops);          /* :48 */
 int pmg_multigrid_set_solvers(pmg_multigrid mg, const pmg_chebyshev* smoothers);      /* :44 */
 int pmg_multigrid_set_interpolators(pmg_multigrid mg, const pmg_interpolator* interp); /* :50-53 */
+/* set_coarse_solver, :46,106-109: the coarsest level is solved by `coarse` -- pmg_cg_solve on
+ * operator[0] from a zero initial guess with the solver's own iteration cap and tolerance --
+ * instead of smoother[0]; NULL restores the smoother.  The reference's coarse solver is a Krylov
+ * solve too (PETSc KSPCG, at most 60 iterations, src/amg.hpp:36-44) but preconditioned by hypre
+ * BoomerAMG, third-party arithmetic that is out of scope here: the library's CG is
+ * Jacobi-preconditioned.  `coarse` must live on the coarsest layout and outlive `mg`. */
+int pmg_multigrid_set_coarse_solver(pmg_multigrid mg, pmg_cg coarse);
 /* apply(x = rhs, y = initial guess in / result out, verbose), :56-155.  If
  * rnorm is non-NULL the final residual norm ||b - A y|| is computed (the
  * reference prints it when verbose, :147-150) -- this costs one extra apply and a

@@ -447,6 +447,7 @@ public:
     check(pmg_cg_residual(_s, &r));
     return r;
   }
+  pmg_cg handle() const { return _s; }
 
 private:
   std::pair<std::vector<double>, std::vector<double>> coefficients() const
@@ -548,13 +549,14 @@ public:
     _solvers = solvers;
     _wired = false;
   }
-  /// Only nullptr: the PETSc/hypre coarse solver of src/amg.hpp is out of scope,
-  /// the coarsest level uses its smoother like src/pmg.hpp:106-109 without one.
-  template <typename CoarseSolver>
-  void set_coarse_solver(std::shared_ptr<CoarseSolver> solver) // :46
+  /// A CGSolver on the coarsest map (its iteration cap and tolerance apply; zero initial guess,
+  /// like the reference's KSP solve, src/amg.hpp:36-44) or nullptr for the smoother
+  /// (src/pmg.hpp:106-109).  The hypre BoomerAMG preconditioner of the reference's coarse
+  /// solver is third-party and out of scope: this CG is Jacobi-preconditioned.
+  void set_coarse_solver(std::shared_ptr<CGSolver<V>> solver) // :46
   {
-    if (solver)
-      throw std::runtime_error("MultigridPreconditioner: only the smoother is available as coarse solver");
+    _coarse = std::move(solver);
+    check(pmg_multigrid_set_coarse_solver(_mg, _coarse ? _coarse->handle() : nullptr));
   }
   void set_operators(std::vector<std::shared_ptr<Operator>>& operators) // :48
   {
@@ -609,6 +611,7 @@ private:
   std::vector<std::shared_ptr<Operator>> _operators;
   std::vector<std::shared_ptr<Solver>> _solvers;
   std::vector<std::shared_ptr<Interp>> _interpolators;
+  std::shared_ptr<CGSolver<V>> _coarse;
   pmg_multigrid _mg = nullptr;
   bool _wired = false;
 };

@@ -104,6 +104,7 @@ _SIGS = {
     "pmg_multigrid_set_operators": (C.c_int, [vp, C.POINTER(vp)]),
     "pmg_multigrid_set_solvers": (C.c_int, [vp, C.POINTER(vp)]),
     "pmg_multigrid_set_interpolators": (C.c_int, [vp, C.POINTER(vp)]),
+    "pmg_multigrid_set_coarse_solver": (C.c_int, [vp, vp]),
     "pmg_multigrid_apply": (C.c_int, [vp, vp, vp, c_dp, vp]),
     "pmg_multigrid_apply_counts": (C.c_int, [vp, C.POINTER(C.c_int), C.c_int]),
 }

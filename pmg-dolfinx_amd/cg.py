@@ -18,6 +18,10 @@ class CGSolver:
         self._handle = h
         self._max_iter = 0
 
+    @property
+    def handle(self):
+        return self._handle
+
     def set_max_iterations(self, max_iter: int):  # :107-113
         self._max_iter = int(max_iter)
         call("pmg_cg_set_max_iterations", self._handle, int(max_iter))

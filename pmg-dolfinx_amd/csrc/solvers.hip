@@ -59,6 +59,7 @@ struct pmg_multigrid_s
   std::vector<pmg_interpolator> interps;
   std::vector<double*> u, b; // per level (finest level uses the caller's vectors)
   std::vector<int> counts;
+  pmg_cg coarse = nullptr;   // optional Krylov coarse solver (src/pmg.hpp:106-107)
 };
 
 namespace
@@ -145,7 +146,14 @@ int mg_apply(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStr
   {
     const double* b0 = (L == 1) ? rhs : mg->b[0];
     const bool zero = (L == 1) ? y_zero : true;
-    PMG_TRY(cheb_solve(mg->smoothers[0], mg->ops[0], mg->u[0], b0, false, zero, s)); // :109
+    if (mg->coarse && L > 1) // :106-107, KSP-style: zero initial guess
+    {
+      PMG_HIP(hipMemsetAsync(mg->u[0], 0, sizeof(double) * mg->layouts[0]->total(), s));
+      int its = 0;
+      PMG_TRY(pmg_cg_solve(mg->coarse, mg->ops[0], mg->u[0], b0, nullptr, &its, (pmg_stream)s));
+    }
+    else
+      PMG_TRY(cheb_solve(mg->smoothers[0], mg->ops[0], mg->u[0], b0, false, zero, s)); // :109
   }
   for (int i = 0; i < L - 1; ++i)
   {
@@ -396,6 +404,15 @@ extern "C" int pmg_multigrid_create(pmg_multigrid* out, int nlevels, const pmg_l
     PMG_TRY(alloc_vec(layouts[i], &mg->b[i]));
   }
   *out = guard.release();
+  return PMG_OK;
+}
+
+extern "C" int pmg_multigrid_set_coarse_solver(pmg_multigrid mg, pmg_cg coarse)
+{
+  PMG_REQUIRE(mg, "pmg_multigrid_set_coarse_solver: NULL argument");
+  PMG_REQUIRE(!coarse || coarse->layout == mg->layouts[0],
+              "pmg_multigrid_set_coarse_solver: the solver is not on the coarsest layout");
+  mg->coarse = coarse;
   return PMG_OK;
 }
 

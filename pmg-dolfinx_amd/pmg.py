@@ -41,10 +41,17 @@ class MultigridPreconditioner:
         self._set("pmg_multigrid_set_interpolators", interpolators, "interpolators")
 
     def set_coarse_solver(self, solver):  # :46
-        if solver is not None:
-            raise NotImplementedError(
-                "AMG coarse solve (src/amg.hpp: PETSc KSPCG + hypre BoomerAMG) is out of scope; "
-                "the coarsest level uses its smoother as in src/pmg.hpp:108-109")
+        """``solver``: a :class:`CGSolver` on the coarsest layout (its iteration cap and tolerance
+        apply; zero initial guess, like the reference's KSP solve) or ``None`` for the smoother
+        (``src/pmg.hpp:106-109``).  The reference's coarse solver is PETSc KSPCG + hypre BoomerAMG
+        (``src/amg.hpp``); the AMG preconditioner is third-party and out of scope, the Krylov
+        method here is the library's Jacobi-preconditioned CG."""
+        from .cg import CGSolver
+
+        if solver is not None and not isinstance(solver, CGSolver):
+            raise TypeError("the coarse solver must be a CGSolver (hypre/PETSc AMG is out of scope) or None")
+        self._keep["coarse"] = solver
+        call("pmg_multigrid_set_coarse_solver", self._handle, solver.handle if solver is not None else None)
 
     def apply(self, x: Vector, y: Vector, verbose: bool = False):  # :56-155
         """``x`` is the right-hand side, ``y`` the initial guess on entry and the

@@ -93,3 +93,12 @@ def test_cpp_adapter_selftest(built):
     the reference's error behaviour, checked inside the C++ program itself."""
     out = run("selftest_main")
     assert "adapter selftest passed" in out
+
+
+def test_pmg_driver_coarse_cg(built):
+    """--coarse-cg: the role of the reference driver's --amg (a Krylov coarse solver in the cycle)."""
+    args = ("--n", 24, "--orders", "1,2", "--smoother-its", 2, "--cycles", 4)
+    plain = grab(r"Cycle \d+: residual norm = (\S+)", run("pmg_main", *args))
+    krylov = grab(r"Cycle \d+: residual norm = (\S+)", run("pmg_main", *args, "--coarse-cg"))
+    assert len(plain) == len(krylov) == 4
+    assert krylov[-1] < 0.1 * plain[-1]

@@ -435,3 +435,60 @@ def test_irregular_numbering(pm, P, pc):
     vc2 = pm.Vector(Lc)
     ip.reverse_interpolate(vx, vc2)
     assert _relerr(vc2.data_copy(), oi.reverse_interpolate(u)) < 1e-12
+
+
+def test_vcycle_with_krylov_coarse_solver(pm):
+    """set_coarse_solver (src/pmg.hpp:46,106-107): the coarsest level solved by CG from a zero
+    initial guess (the reference: KSPCG, at most 60 iterations, src/amg.hpp:36-44 -- its hypre
+    preconditioner is out of scope, here and in the oracle the CG is Jacobi-preconditioned)."""
+    from oracle import pmg_oracle as po
+
+    n, orders, k = 6, (1, 2, 4), 3
+    h = pm.PoissonHierarchy(n, orders, kappa=2.0, cheb_its=k, warp=warp)
+    mesh, ops, sm, it, mg, b, eigs = po.build_hierarchy(n, orders, cheb_its=k, warp=warp)
+    for s, e in zip(sm, h.eig_ranges):
+        s.eig_range = e
+    ccg = pm.CGSolver(h.layouts[0])
+    ccg.set_max_iterations(12)  # a fixed count (rtol 0): identical arithmetic on both sides
+    ccg.set_tolerance(0.0)
+    h.mg.set_coarse_solver(ccg)
+
+    def coarse(u0, b0):
+        cg = po.CGSolver()
+        cg.set_max_iterations(12)
+        cg.set_tolerance(0.0)
+        u0[:] = 0.0
+        cg.solve(ops[0], u0, b0)
+
+    mgo = po.MultigridPreconditioner(ops, sm, it, mesh.boundary_marker(orders[0]), coarse_solver=coarse)
+    x = h.new_vector()
+    x.set(0.0)
+    xo = np.zeros_like(b)
+    rn_cg = []
+    for _ in range(3):
+        rn = h.mg.apply(h.rhs[-1], x, verbose=True)
+        xo = mgo.apply(b, xo, compute_rnorm=True)
+        assert _relerr(x.data_copy(), xo) < 1e-9
+        assert abs(rn - mgo.rnorm) < 1e-8 * mgo.rnorm
+        rn_cg.append(rn)
+    with pytest.raises(TypeError):
+        h.mg.set_coarse_solver(h.smoothers[0])
+    wrong = pm.CGSolver(h.layouts[1])
+    with pytest.raises(RuntimeError, match="coarsest layout"):
+        h.mg.set_coarse_solver(wrong)
+    # the reference's settings (60 iterations, rtol 1e-5) on a mesh whose coarse level is too big for
+    # three smoother steps: the stationary iteration converges much faster with the Krylov coarse solve
+    h2 = pm.PoissonHierarchy(24, (1, 2), kappa=2.0, cheb_its=2)
+    x2 = h2.new_vector()
+    x2.set(0.0)
+    rs = [h2.mg.apply(h2.rhs[-1], x2, verbose=True) for _ in range(4)]
+    c2 = pm.CGSolver(h2.layouts[0])
+    c2.set_max_iterations(60)
+    c2.set_tolerance(1e-5)
+    h2.mg.set_coarse_solver(c2)
+    x2.set(0.0)
+    r60 = [h2.mg.apply(h2.rhs[-1], x2, verbose=True) for _ in range(4)]
+    assert r60[-1] < 0.1 * rs[-1], (r60, rs)
+    h2.mg.set_coarse_solver(None)
+    x2.set(0.0)
+    assert abs(h2.mg.apply(h2.rhs[-1], x2, verbose=True) - rs[0]) < 1e-12 * rs[0]  # NULL restores the smoother
