@@ -41,7 +41,8 @@ def log(*a):
 
 class extra:
     """An extra measurement must never cost the headline line: a failure inside the block is
-    logged and recorded under its key instead of propagating."""
+    logged and recorded under its key instead of propagating.  Only on one rank: with several
+    ranks a swallowed failure would leave the others waiting in a collective, so it propagates."""
 
     def __init__(self, out, key):
         self.out, self.key = out, key
@@ -50,7 +51,7 @@ class extra:
         return self
 
     def __exit__(self, et, ev, tb):
-        if et is not None and issubclass(et, Exception):
+        if et is not None and issubclass(et, Exception) and int(os.environ.get("WORLD_SIZE", "1")) == 1:
             import traceback
 
             log(f"extra measurement '{self.key}' failed:")
