@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-affine", action="store_true", help="skip the extra affine-geometry measurement")
     ap.add_argument("--no-sweep", action="store_true", help="skip the operator-apply sweep over degrees (N = 1 only)")
+    ap.add_argument("--extras", action="store_true",
+                    help="N > 1: also run the extra measurements (PCG, affine mode); by default only N = 1 does")
     args = ap.parse_args()
 
     import numpy as np
@@ -213,8 +215,10 @@ def main():
                       "seconds": t_pcg, "true_relative_residual": pm.norm(rr) / pm.norm(b)}
         del cg, xs, rr
 
-    with extra(out, "pcg"):
-        _pcg()
+    extras = world == 1 or args.extras  # the scaling runs measure the headline only
+    if extras:
+        with extra(out, "pcg"):
+            _pcg()
 
     # ---- extra, reported separately and never mixed into `value`/`roofline`: the same V-cycle with the
     # affine-cell geometry mode (one constant tensor per cell instead of the stored G stream; byte model
@@ -262,8 +266,9 @@ def main():
             }
             del xa
 
-    with extra(out, "affine_geometry"):
-        _affine_geometry()
+    if extras:
+        with extra(out, "affine_geometry"):
+            _affine_geometry()
 
     # ---- BASELINE config 4 (extra, N = 1): operator apply alone for p in {2, 4, 6, 8} at ~17 M dofs, same
     # byte model and timing hook as `roofline` ----
