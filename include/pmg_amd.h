@@ -239,7 +239,8 @@ int pmg_interpolator_create(pmg_interpolator* out, pmg_layout layout_coarse,
 /* Same, sharing the cell patches (grouping, colours, launch order) of the
  * fine-level operator: both transfers then run one workgroup per patch with LDS
  * accumulation -- no global atomics, no zero-fill -- and the prolongation can be
- * fused with the correction.  fine_operator may be NULL (== pmg_interpolator_create). */
+ * fused with the correction.  fine_operator may be NULL (== pmg_interpolator_create);
+ * otherwise it must outlive the interpolator, which reads its patch tables. */
 int pmg_interpolator_create_with_operator(pmg_interpolator* out, pmg_layout layout_coarse,
                                           pmg_layout layout_fine, int degree_coarse,
                                           int degree_fine, int32_t ncells,

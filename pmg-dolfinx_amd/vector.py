@@ -20,7 +20,6 @@ import numpy as np
 from . import _lib
 from ._lib import call, current_stream, ptr, vp
 
-_REGISTRY = {}  # id -> Layout, keeps callbacks' targets alive
 
 
 def _dist():
@@ -89,7 +88,6 @@ class Layout:
         if self.distributed:
             self._cb_allreduce_max = _lib.ALLREDUCE_FN(lambda user, values, n: self._allreduce(user, values, n, "max"))
             call("pmg_layout_set_allreduce_max", h, self._cb_allreduce_max)
-        _REGISTRY[id(self)] = self
 
     # ---- per-rank split sizes for all_to_all_single ----
     def _splits(self):
@@ -200,7 +198,6 @@ class Layout:
             if self._handle is not None:
                 _lib.lib().pmg_layout_destroy(self._handle)
                 self._handle = None
-            _REGISTRY.pop(id(self), None)
         except Exception:
             pass
 
