@@ -150,19 +150,43 @@ __device__ inline void jacobian(const double* __restrict__ xgeom,
   detJ = J[0][0] * K[0][0] + J[0][1] * K[1][0] + J[0][2] * K[2][0];
 }
 
-// Position of (quadrature point q = (a,b,c), component pair) inside a slot's G
-// block of 3*N double2: block kernel [pair][q]; column kernel [c][pair][a*nd+b].
-__device__ __forceinline__ int gidx(int column, int nd, int N, int q, int pair)
+// Layout of the stored geometry tensor G (double2 pairs (G00,G01)(G02,G11)(G12,G22)).
+//   block kernel : [slot][pair][q]
+//   column kernel: [slot][layer c][pair][a*nd+b]
+//   flat (column kernel, degrees in PMG_GFLAT_MASK): [patch][item][layer c][pair][cell of the item][a*nd+b],
+//     every (item, layer) block padded to whole 128-byte lines -- a wavefront then reads its item's
+//     layer as NJ full-width loads of 64 consecutive double2 (whole lines, none shared between two
+//     load instructions) and hands the values to the lanes that use them through LDS.  Pays where
+//     the per-cell planes are short and misaligned: P = 2 (seven 144-byte pieces per load
+//     instruction otherwise), 765 -> 674 us at 128^3; slower at P = 1, 3, 4 (1485 -> 1524, 513 -> 549,
+//     458 -> 480 us), so only P = 2 uses it.
+#ifndef PMG_GFLAT_MASK
+#define PMG_GFLAT_MASK (1 << 2) // bit P
+#endif
+__host__ __device__ constexpr bool gflat(int nd) { return nd * nd <= 64 && ((PMG_GFLAT_MASK >> (nd - 1)) & 1); }
+__host__ __device__ constexpr int gcw(int nd) { return nd * nd <= 64 ? 64 / (nd * nd) : 1; }
+__host__ __device__ constexpr int gls(int nd) { return ((3 * gcw(nd) * nd * nd + 7) / 8) * 8; } // layer stride
+__host__ __device__ constexpr long long gpatch(int column, int nd, int K)
 {
+  return (column && gflat(nd)) ? (long long)((K + gcw(nd) - 1) / gcw(nd)) * nd * gls(nd)
+                               : (long long)K * 3 * nd * nd * nd;
+}
+// absolute position of (patch slot, quadrature point q = (a,b,c), component pair)
+__device__ __forceinline__ size_t gpos(int column, int nd, int K, long long slot, int q, int pair)
+{
+  const int nsq = nd * nd, N = nsq * nd;
   if (!column)
-    return pair * N + q;
-  const int nsq = nd * nd;
+    return (size_t)slot * 3 * N + pair * N + q;
   const int a = q / nsq, b = (q - a * nsq) / nd, c = q - a * nsq - b * nd;
-  return (c * 3 + pair) * nsq + a * nd + b;
+  if (!gflat(nd))
+    return (size_t)slot * 3 * N + (c * 3 + pair) * nsq + a * nd + b;
+  const long long p = slot / K;
+  const int sl = (int)(slot - p * K), cw = gcw(nd), item = sl / cw, ci = sl - item * cw;
+  return (size_t)p * gpatch(1, nd, K) + (size_t)(item * nd + c) * gls(nd) + pair * (cw * nsq) + ci * nsq + a * nd + b;
 }
 
 // G for every (patch slot, q), paired layout
-__global__ void geometry_kernel(long long nslots, int nd, int column,
+__global__ void geometry_kernel(long long nslots, int nd, int column, int K,
                                 const int32_t* __restrict__ pcell,
                                 const double* __restrict__ xgeom,
                                 const int32_t* __restrict__ geom_dofmap,
@@ -189,10 +213,9 @@ __global__ void geometry_kernel(long long nslots, int nd, int column,
     g4 = (K[2][0] * K[1][0] + K[2][1] * K[1][1] + K[2][2] * K[1][2]) * s;
     g5 = (K[2][0] * K[2][0] + K[2][1] * K[2][1] + K[2][2] * K[2][2]) * s;
   }
-  double2* Gc = G + (size_t)slot * 3 * nq;
-  Gc[gidx(column, nd, nq, q, 0)] = make_double2(g0, g1);
-  Gc[gidx(column, nd, nq, q, 1)] = make_double2(g2, g3);
-  Gc[gidx(column, nd, nq, q, 2)] = make_double2(g4, g5);
+  G[gpos(column, nd, K, slot, q, 0)] = make_double2(g0, g1);
+  G[gpos(column, nd, K, slot, q, 1)] = make_double2(g2, g3);
+  G[gpos(column, nd, K, slot, q, 2)] = make_double2(g4, g5);
 }
 
 // Constant geometry tensor of an affine cell: K K^T / detJ at the cell centre
@@ -245,7 +268,7 @@ __global__ void affine_geometry_kernel(long long nslots, const int32_t* __restri
 }
 
 // paired slot layout -> the reference's [cell][q][6]
-__global__ void geometry_export_kernel(long long nslots, int nd, int column,
+__global__ void geometry_export_kernel(long long nslots, int nd, int column, int K,
                                        const int32_t* __restrict__ pcell,
                                        const double2* __restrict__ G, double* __restrict__ out)
 {
@@ -258,9 +281,8 @@ __global__ void geometry_export_kernel(long long nslots, int nd, int column,
   int c = pcell[slot];
   if (c < 0)
     return;
-  const double2* Gc = G + (size_t)slot * 3 * nq;
-  double2 a = Gc[gidx(column, nd, nq, q, 0)], b = Gc[gidx(column, nd, nq, q, 1)],
-          d = Gc[gidx(column, nd, nq, q, 2)];
+  double2 a = G[gpos(column, nd, K, slot, q, 0)], b = G[gpos(column, nd, K, slot, q, 1)],
+          d = G[gpos(column, nd, K, slot, q, 2)];
   double* o = out + ((size_t)c * nq + q) * 6;
   o[0] = a.x;
   o[1] = a.y;
@@ -542,6 +564,10 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
   __shared__ double sq[NG * WL];
   __shared__ double sgr[NG * WL];
   __shared__ double sgs[NG * WL];
+  // flat G layout: one layer of the item, as loaded (NJ x 64 double2), for the hand-over to the lanes
+  constexpr bool FLAT = !AFF && WPC == 1 && gflat(ND);
+  constexpr int FL = 3 * WL, NJ = (FL + 63) / 64, LS = gls(ND);
+  __shared__ double2 sgb[FLAT ? NG * NJ * 64 : 1];
 
   const int p = first + blockIdx.x;
   const int t = threadIdx.x;
@@ -660,6 +686,16 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
     // affine cells (AFF): G_q = w_a w_b w_c * Gc with one constant tensor Gc per cell.
     constexpr int GD = ND < PMG_GDEPTH ? ND : PMG_GDEPTH;
     double2 gq[AFF ? 1 : GD][3];
+    double2 gfl[FLAT ? NJ : 1]; // flat layout: the next layer as loaded
+    // (only used when FLAT; the item index is wave-uniform: a scalar base plus 32-bit lane offsets)
+    const double2* Gi = G + (size_t)p * gpatch(1, ND, K) + (size_t)__builtin_amdgcn_readfirstlane(it) * ND * LS;
+    int eo[FLAT ? NJ : 1]; // the lane's elements of a layer (clamped: the tail lanes re-read the last one)
+    if constexpr (FLAT)
+    {
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+        eo[jj] = lane + 64 * jj < FL ? lane + 64 * jj : FL - 1;
+    }
     double gc[6] = {0, 0, 0, 0, 0, 0};
     if constexpr (AFF)
     {
@@ -667,6 +703,12 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
 #pragma unroll
       for (int d = 0; d < 6; ++d)
         gc[d] = ga[d];
+    }
+    else if constexpr (FLAT)
+    {
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+        gfl[jj] = gload<NT>(Gi + eo[jj]);
     }
     else
     {
@@ -696,6 +738,23 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
         g01 = make_double2(sc * gc[0], sc * gc[1]);
         g23 = make_double2(sc * gc[2], sc * gc[3]);
         g45 = make_double2(sc * gc[4], sc * gc[5]);
+      }
+      else if constexpr (FLAT)
+      {
+        double2* gb = sgb + wave * (NJ * 64);
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+          gb[lane + 64 * jj] = gfl[jj]; // as loaded ...
+        wave_fence();
+        g01 = gb[lw]; // ... and as used: [pair][cell of the item][column]
+        g23 = gb[WL + lw];
+        g45 = gb[2 * WL + lw];
+        if (k + 1 < ND)
+        {
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj)
+            gfl[jj] = gload<NT>(Gi + (k + 1) * LS + eo[jj]);
+        }
       }
       else
       {
@@ -797,7 +856,7 @@ __global__ void zero_list_kernel(int n, const int32_t* __restrict__ idx, double*
 }
 
 // ---- matrix-free diagonal (replaces the CSR detour of examples/pmg/main.cpp:274-279) ----
-__global__ void diagonal_kernel(long long nslots, int nd, int column,
+__global__ void diagonal_kernel(long long nslots, int nd, int column, int K,
                                 const int32_t* __restrict__ pcell,
                                 const double2* __restrict__ G, const int32_t* __restrict__ dofmap,
                                 const int8_t* __restrict__ bc, const double* __restrict__ kappa,
@@ -813,19 +872,18 @@ __global__ void diagonal_kernel(long long nslots, int nd, int column,
   if (cell < 0)
     return;
   int a = t / nsq, b = (t - a * nsq) / nd, c = t - a * nsq - b * nd;
-  const double2* Gc = G + (size_t)slot * 3 * N;
+  auto Gq = [&](int q, int pair) { return G[gpos(column, nd, K, slot, q, pair)]; };
   double s = 0.0;
   for (int q = 0; q < nd; ++q)
   {
     double da = D[q * nd + a], db = D[q * nd + b], dc = D[q * nd + c];
-    s += da * da * Gc[gidx(column, nd, N, q * nsq + b * nd + c, 0)].x; // G00 at (q,b,c)
-    s += db * db * Gc[gidx(column, nd, N, a * nsq + q * nd + c, 1)].y; // G11 at (a,q,c)
-    s += dc * dc * Gc[gidx(column, nd, N, a * nsq + b * nd + q, 2)].y; // G22 at (a,b,q)
+    s += da * da * Gq(q * nsq + b * nd + c, 0).x; // G00 at (q,b,c)
+    s += db * db * Gq(a * nsq + q * nd + c, 1).y; // G11 at (a,q,c)
+    s += dc * dc * Gq(a * nsq + b * nd + q, 2).y; // G22 at (a,b,q)
   }
   double daa = D[a * nd + a], dbb = D[b * nd + b], dcc = D[c * nd + c];
   s += 2.0
-       * (Gc[gidx(column, nd, N, t, 0)].y * daa * dbb + Gc[gidx(column, nd, N, t, 1)].x * daa * dcc
-          + Gc[gidx(column, nd, N, t, 2)].x * dbb * dcc);
+       * (Gq(t, 0).y * daa * dbb + Gq(t, 1).x * daa * dcc + Gq(t, 2).x * dbb * dcc);
   int32_t dof = dofmap[(size_t)cell * N + t];
   if (!bc[dof])
     atomicAdd(&diag[dof], kappa[cell] * s);
@@ -1180,14 +1238,18 @@ extern "C" int pmg_laplacian_create_with_tables(
   if (nslots > 0)
     affine_geometry_kernel<<<(unsigned)((nslots + 255) / 256), 256, 0, s>>>(nslots, op->pcell, xgeom,
                                                                            geom_dofmap, op->Gaff);
-  PMG_HIP(hipMalloc(&op->G, sizeof(double2) * 3 * (nq_total ? nq_total : 1)));
+  {
+    const size_t gsize = (size_t)op->npatch * gpatch(column_layout(degree) ? 1 : 0, nd, op->K);
+    PMG_HIP(hipMalloc(&op->G, sizeof(double2) * (gsize ? gsize : 1)));
+    PMG_HIP(hipMemsetAsync(op->G, 0, sizeof(double2) * (gsize ? gsize : 1), s)); // padding, empty slots
+  }
   PMG_HIP(hipMalloc(&op->diag_inv, sizeof(double) * (total ? total : 1)));
   PMG_HIP(hipEventCreate(&op->ev0));
   PMG_HIP(hipEventCreate(&op->ev1));
   if (nq_total > 0)
   {
     long long blocks = (nq_total + 255) / 256;
-    geometry_kernel<<<(unsigned)blocks, 256, 0, s>>>(nslots, nd, column_layout(degree) ? 1 : 0,
+    geometry_kernel<<<(unsigned)blocks, 256, 0, s>>>(nslots, nd, column_layout(degree) ? 1 : 0, op->K,
                                                     op->pcell, xgeom, geom_dofmap, op->dphi_geom,
                                                     op->gweights, op->G);
     PMG_HIP(hipGetLastError());
@@ -1288,7 +1350,7 @@ extern "C" int pmg_laplacian_compute_diag_inverse(pmg_laplacian op, pmg_stream s
   const long long n = nslots * op->N;
   if (n > 0)
     diagonal_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
-        nslots, op->nd, column_layout(op->P) ? 1 : 0, op->pcell, op->G, op->dofmap, op->bc,
+        nslots, op->nd, column_layout(op->P) ? 1 : 0, op->K, op->pcell, op->G, op->dofmap, op->bc,
         op->kappa, op->D, op->diag_inv);
   if (total > 0)
     diag_invert_kernel<<<(total + 255) / 256, 256, 0, s>>>(total, op->bc, op->diag_inv);
@@ -1306,7 +1368,7 @@ extern "C" int pmg_laplacian_get_geometry(pmg_laplacian op, double* G_out, pmg_s
   const long long n = nslots * op->N;
   if (n > 0)
     geometry_export_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
-        nslots, op->nd, column_layout(op->P) ? 1 : 0, op->pcell, op->G, G_out);
+        nslots, op->nd, column_layout(op->P) ? 1 : 0, op->K, op->pcell, op->G, G_out);
   PMG_HIP(hipGetLastError());
   return PMG_OK;
 }

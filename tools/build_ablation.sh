@@ -8,6 +8,7 @@
 #   -DPMG_DLDS_FROM=<P from which the 1-D tables are re-read from LDS>     [9 = never]
 #   -DPMG_COLUMN_MAX=<highest P on the column kernel; above: block kernel> [8]
 #   -DPMG_BLOCK_WPS=<min waves per SIMD of the block kernel>               [1]
+#   -DPMG_GFLAT_MASK=<bit P: flat, line-aligned G layout>                 [1<<2]
 #   -DPMG_NO_NT                                   default cache policy instead of nt G loads / y stores
 #   -DPMG_P4_BZ4, -DPMG_P1_SHAPE={bx,by,bz,cpr,max_m}, -DPMG_P2_SHAPE=...  patch shapes
 #   -DPMG_STAMPS                                  per-workgroup phase stamps (tools/stamp_phases.py)
