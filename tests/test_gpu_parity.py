@@ -237,7 +237,8 @@ def test_transfer_parity(pm, pc, pf, n, warped, patched):
             ip.interpolate_add(vc, pm.Vector(Lf))
 
 
-@pytest.mark.parametrize("orders,n", [((1, 2, 4), 4), ((1, 3), 5), ((2, 4), (3, 4, 2)), ((3,), 3)])
+@pytest.mark.parametrize("orders,n", [((1, 2, 4), 4), ((1, 3), 5), ((2, 4), (3, 4, 2)), ((3,), 3),
+                                      ((1, 3, 6), 3), ((1, 2, 4, 8), 3)])  # (1, 3, 6): BASELINE config 5's levels
 def test_vcycle_parity(pm, orders, n):
     from oracle import pmg_oracle as po
 
