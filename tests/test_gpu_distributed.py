@@ -81,21 +81,24 @@ def _worker(rank, world, port, n, dims, orders, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dims,n", [((1, 1, 2), (3, 4, 8)), ((2, 1, 1), (6, 3, 4))])
-def test_two_ranks_one_gpu(dims, n, built):
+@pytest.mark.parametrize("dims,n", [((1, 1, 2), (3, 4, 8)), ((2, 1, 1), (6, 3, 4)), ((1, 2, 2), (3, 4, 6))])
+def test_ranks_share_one_gpu(dims, n, built):
+    """Two ranks (one neighbour each) and four ranks (three neighbours each, edge and corner
+    exchanges) on the one GPU."""
     import torch
     import torch.multiprocessing as mp
 
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    orders = (1, 2, 4)
+    orders = (1, 2, 4) if dims[0] * dims[1] * dims[2] == 2 else (1, 2)
+    world = dims[0] * dims[1] * dims[2]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, dims, orders, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, orders, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(2)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
