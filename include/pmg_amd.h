@@ -193,8 +193,11 @@ int pmg_laplacian_degree(pmg_laplacian op);
  * separate from storedG).  Fails if the mesh has a non-affine cell. */
 int pmg_laplacian_is_affine(pmg_laplacian op);
 int pmg_laplacian_set_geometry_mode(pmg_laplacian op, int mode);
-/* One operator application issues one stiffness-kernel launch per patch colour
- * and cell list (8 on a structured single-rank box). */
+/* One operator application issues one stiffness-kernel launch per patch colour of the
+ * interior cell list (8 on a structured box) plus one for the boundary list; on a small
+ * level -- fewer patch dofs in the interior list than 2 M (degree <= 2) / 6 M (degree >= 3),
+ * environment variable PMG_MERGE_BELOW overrides -- the colours are merged into one launch
+ * that accumulates with atomics. */
 int pmg_laplacian_launches_per_apply(pmg_laplacian op);
 /* Dominant-kernel timing hook for bench.py: enqueue `reps` times every
  * stiffness-kernel launch of one operator application (no halo, no zero-fill)
