@@ -58,7 +58,9 @@ inline constexpr PatchShape patch_shape(int P)
   case 3:
     return {2, 2, 8, 4, 1280};   // M = 7*7*25  = 1225
   case 4:
-#ifdef PMG_P4_BZ4
+#if defined(PMG_P4_SHAPE)
+    return PMG_P4_SHAPE; // tuning build
+#elif defined(PMG_P4_BZ4)
     return {2, 2, 4, 4, 1408};   // M = 9*9*17  = 1377 (tuning build)
 #else
     return {2, 2, 8, 4, 2688};   // M = 9*9*33  = 2673

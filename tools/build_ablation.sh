@@ -10,7 +10,7 @@
 #   -DPMG_BLOCK_WPS=<min waves per SIMD of the block kernel>               [1]
 #   -DPMG_GFLAT_MASK=<bit P: flat, line-aligned G layout>                 [1<<2]
 #   -DPMG_NO_NT                                   default cache policy instead of nt G loads / y stores
-#   -DPMG_P4_BZ4, -DPMG_P1_SHAPE={bx,by,bz,cpr,max_m}, -DPMG_P2_SHAPE=...  patch shapes
+#   -DPMG_P4_BZ4, -DPMG_P1_SHAPE={bx,by,bz,cpr,max_m}, -DPMG_P2_SHAPE=..., -DPMG_P4_SHAPE=...  patch shapes
 #   -DPMG_STAMPS                                  per-workgroup phase stamps (tools/stamp_phases.py)
 # Select a build at run time with PMG_AMD_LIB=tools/abl/libpmg_amd_NAME.so.
 set -e
