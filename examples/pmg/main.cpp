@@ -179,6 +179,7 @@ int main(int argc, char** argv)
       acc::CGSolver<DeviceVector> cg(maps.back(), 1);
       cg.set_max_iterations(100);
       cg.set_tolerance(1e-8);
+      cg.set_flexible(coarse_cg); // the cycle is not a fixed linear operator with a Krylov coarse solve
       x.set(0.0);
       const int its = cg.solve(*operators.back(), x, *bs.back(), pmg, false);
       DeviceVector Ax(maps.back(), 1), r(maps.back(), 1);

@@ -225,6 +225,10 @@ int pmg_cg_store_coefficients(pmg_cg s, int flag);
  * Jacobi preconditioner (not in the reference). */
 int pmg_cg_solve(pmg_cg s, pmg_laplacian A, double* x, const double* b, pmg_multigrid precond,
                  int* iterations, pmg_stream stream);
+/* Flexible variant (not in the reference): with a V-cycle preconditioner that is not a fixed
+ * linear operator -- a Krylov coarse solver inside -- beta = r_new.(z_new - z_old) / r_old.z_old
+ * keeps the recurrence residual honest.  No effect without `precond`. */
+int pmg_cg_set_flexible(pmg_cg s, int flag);
 /* alphas()/betas(), :118-119; returns the number stored. */
 int pmg_cg_coefficients(pmg_cg s, double* alphas, double* betas, int capacity);
 /* compute_eigenvalues(), :121-142: sorted ascending; returns the count or <0. */

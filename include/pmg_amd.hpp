@@ -412,6 +412,8 @@ public:
   void set_max_iterations(int n) { check(pmg_cg_set_max_iterations(_s, n)); } // :110
   void set_tolerance(double rtol) { check(pmg_cg_set_tolerance(_s, rtol)); }  // :113
   void store_coefficients(bool flag) { check(pmg_cg_store_coefficients(_s, flag ? 1 : 0)); } // :116
+  /// Polak-Ribiere beta for a V-cycle preconditioner with a Krylov coarse solver (not in the reference).
+  void set_flexible(bool flag) { check(pmg_cg_set_flexible(_s, flag ? 1 : 0)); }
   /// Jacobi-preconditioned CG (:147-222); returns the iteration count.
   template <typename Operator>
   int solve(Operator& A, V& x, const V& b, bool /*verbose*/ = false)

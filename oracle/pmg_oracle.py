@@ -484,15 +484,18 @@ class CGSolver:
     def store_coefficients(self, v):
         self.store = bool(v)
 
-    def solve(self, A, x, b, precond=None):
+    def solve(self, A, x, b, precond=None, flexible=False):
         """``precond`` (optional, not in the reference): callable r -> M^-1 r that
         replaces the hard-wired Jacobi ``pointwise_mult`` of ``:161,192`` (SURVEY.md
-        8f-3: the V-cycle from a zero initial guess)."""
+        8f-3: the V-cycle from a zero initial guess).  ``flexible``: Polak-Ribiere beta
+        ``r_new.(z_new - z_old) / r_old.z_old`` for a preconditioner that is not a fixed
+        linear operator."""
         dinv = A.diag_inverse()
         M = (lambda v: v * dinv) if precond is None else precond
         y = A.apply(x)
         r = b - y
         p = M(r)
+        zold = p.copy()
         rnorm0 = inner_product(p, r)
         rnorm = rnorm0
         rtol2 = self.rtol * self.rtol
@@ -506,6 +509,9 @@ class CGSolver:
             y = M(r)
             rnorm_new = inner_product(r, y)
             beta = rnorm_new / rnorm
+            if flexible and precond is not None:
+                beta = (rnorm_new - inner_product(r, zold)) / rnorm
+                zold = y.copy()
             rnorm = rnorm_new
             if rnorm / rnorm0 < rtol2:
                 break

@@ -83,6 +83,7 @@ _SIGS = {
     "pmg_cg_set_max_iterations": (C.c_int, [vp, C.c_int]),
     "pmg_cg_set_tolerance": (C.c_int, [vp, C.c_double]),
     "pmg_cg_store_coefficients": (C.c_int, [vp, C.c_int]),
+    "pmg_cg_set_flexible": (C.c_int, [vp, C.c_int]),
     "pmg_cg_solve": (C.c_int, [vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]),
     "pmg_cg_coefficients": (C.c_int, [vp, c_dp, c_dp, C.c_int]),
     "pmg_cg_compute_eigenvalues": (C.c_int, [vp, c_dp, C.c_int]),

@@ -32,6 +32,11 @@ class CGSolver:
     def store_coefficients(self, val: bool):  # :116
         call("pmg_cg_store_coefficients", self._handle, int(bool(val)))
 
+    def set_flexible(self, val: bool):
+        """Polak-Ribiere beta for a preconditioner that is not a fixed linear operator (the V-cycle
+        with a Krylov coarse solver); not in the reference."""
+        call("pmg_cg_set_flexible", self._handle, int(bool(val)))
+
     def solve(self, A, x: Vector, b: Vector, verbose: bool = False, preconditioner=None) -> int:  # :147-222
         its = C.c_int()
         call("pmg_cg_solve", self._handle, A.handle, ptr(x.data), ptr(b.data),

@@ -46,6 +46,8 @@ struct pmg_cg_s
   double rtol = 0;
   bool store = false;
   double *r = nullptr, *y = nullptr, *p = nullptr; // src/cg.hpp:101-104
+  double* zold = nullptr;                           // flexible variant only
+  bool flexible = false;
   std::vector<double> alphas, betas, residuals;
 };
 
@@ -239,6 +241,7 @@ extern "C" int pmg_cg_destroy(pmg_cg cg)
   (void)hipFree(cg->r);
   (void)hipFree(cg->y);
   (void)hipFree(cg->p);
+  (void)hipFree(cg->zold);
   delete cg;
   return PMG_OK;
 }
@@ -290,9 +293,16 @@ extern "C" int pmg_cg_solve(pmg_cg cg, pmg_laplacian A, double* x, const double*
     return PMG_OK;
   };
 
+  // Flexible CG (Polak-Ribiere beta) for a preconditioner that is not a fixed linear operator --
+  // the V-cycle with a Krylov coarse solver: one more vector (the previous z), one more dot product
+  const bool flex = cg->flexible && precond;
+  if (flex && !cg->zold)
+    PMG_TRY(alloc_vec(l, &cg->zold));
   PMG_TRY(laplacian_apply(A, x, y, s)); // :159
   launch_axpy(n, r, -1.0, y, b, s);     // :160
   PMG_TRY(precondition(p, r));          // :161
+  if (flex)
+    PMG_HIP(hipMemcpyAsync(cg->zold, p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
   double rnorm0;
   PMG_TRY(dot_host(l, p, r, &rnorm0, s)); // :163
   double rnorm = rnorm0;
@@ -315,7 +325,14 @@ extern "C" int pmg_cg_solve(pmg_cg cg, pmg_laplacian A, double* x, const double*
       launch_cg_update(n, x, r, y, p, dinv, alpha, s); // :186-192 fused
     double rnorm_new;
     PMG_TRY(dot_host(l, r, y, &rnorm_new, s)); // :195
-    const double beta = rnorm_new / rnorm;
+    double beta = rnorm_new / rnorm;
+    if (flex)
+    {
+      double rz_old;
+      PMG_TRY(dot_host(l, r, cg->zold, &rz_old, s));
+      beta = (rnorm_new - rz_old) / rnorm; // r_new . (z_new - z_old) / (r_old . z_old)
+      PMG_HIP(hipMemcpyAsync(cg->zold, y, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    }
     rnorm = rnorm_new;
     if (rnorm / rnorm0 < rtol2) // :206
       break;
@@ -335,6 +352,13 @@ extern "C" int pmg_cg_solve(pmg_cg cg, pmg_laplacian A, double* x, const double*
   if (iterations)
     *iterations = k;
   PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+extern "C" int pmg_cg_set_flexible(pmg_cg cg, int flag)
+{
+  PMG_REQUIRE(cg, "pmg_cg_set_flexible: NULL argument");
+  cg->flexible = flag != 0;
   return PMG_OK;
 }
 

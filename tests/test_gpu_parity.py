@@ -493,3 +493,48 @@ def test_vcycle_with_krylov_coarse_solver(pm):
     h2.mg.set_coarse_solver(None)
     x2.set(0.0)
     assert abs(h2.mg.apply(h2.rhs[-1], x2, verbose=True) - rs[0]) < 1e-12 * rs[0]  # NULL restores the smoother
+
+
+def test_flexible_pcg_with_krylov_coarse_solver(pm):
+    """Outer CG with the Polak-Ribiere beta (pmg_cg_set_flexible) and a V-cycle whose coarsest
+    level is solved by an inner CG -- the preconditioner is then not a fixed linear operator.
+    Against the oracle's flexible PCG with the same inner CG (fixed iteration count)."""
+    from oracle import pmg_oracle as po
+
+    n, orders, k = 8, (1, 2, 4), 2
+    h = pm.PoissonHierarchy(n, orders, kappa=2.0, cheb_its=k, warp=warp)
+    mesh, ops, sm, it, mg, b, eigs = po.build_hierarchy(n, orders, cheb_its=k, warp=warp)
+    for s_, e in zip(sm, h.eig_ranges):
+        s_.eig_range = e
+    ccg = pm.CGSolver(h.layouts[0])
+    ccg.set_max_iterations(8)
+    ccg.set_tolerance(0.0)
+    h.mg.set_coarse_solver(ccg)
+
+    def coarse(u0, b0):
+        c = po.CGSolver()
+        c.set_max_iterations(8)
+        c.set_tolerance(0.0)
+        u0[:] = 0.0
+        c.solve(ops[0], u0, b0)
+
+    mgo = po.MultigridPreconditioner(ops, sm, it, mesh.boundary_marker(orders[0]), coarse_solver=coarse)
+    cg = pm.CGSolver(h.layouts[-1])
+    cg.set_max_iterations(40)
+    cg.set_tolerance(1e-9)
+    cg.set_flexible(True)
+    x = h.new_vector()
+    x.set(0.0)
+    its = cg.solve(h.operators[-1], x, h.rhs[-1], preconditioner=h.mg)
+    ocg = po.CGSolver()
+    ocg.set_max_iterations(40)
+    ocg.set_tolerance(1e-9)
+    xo = np.zeros_like(b)
+    oits = ocg.solve(ops[-1], xo, b, precond=lambda r: mgo.apply(r, np.zeros_like(r)), flexible=True)
+    assert its == oits and its < 15
+    assert _relerr(x.data_copy(), xo) < 1e-8
+    r = pm.Vector(h.layouts[-1])
+    y = pm.Vector(h.layouts[-1])
+    h.operators[-1](x, y)
+    pm.axpy(r, -1.0, y, h.rhs[-1])
+    assert pm.norm(r) < 1e-7 * pm.norm(h.rhs[-1])  # the recurrence residual is honest
