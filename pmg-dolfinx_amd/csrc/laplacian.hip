@@ -103,8 +103,8 @@ struct Shape
   static constexpr int NWMAX = PMG_NW; // tuning build
 #else
   // measured (profiles/kernel_roofline): 4 waves and more workgroups per CU for the
-  // register-heavy degrees, 8 waves otherwise
-  static constexpr int NWMAX = (P == 5 || P == 6 || P == 8) ? 4 : 8;
+  // register-heavy degrees and P = 3 (518 -> 496 us), 8 waves otherwise
+  static constexpr int NWMAX = (P == 3 || P == 5 || P == 6 || P == 8) ? 4 : 8;
 #endif
   static constexpr int NG = ITEMS < NWMAX / WPC ? ITEMS : NWMAX / WPC; // items in flight per workgroup
   static constexpr int NW = NG * WPC;                                  // waves per workgroup

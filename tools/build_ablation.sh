@@ -2,7 +2,7 @@
 # Tuning builds of the library into tools/abl/ (never used by tests or bench).
 # Usage: tools/build_ablation.sh NAME "-DFLAG ..." [NAME FLAGS ...]
 # Flags understood by laplacian.hip / patches.hpp (defaults in brackets):
-#   -DPMG_NW=<max waves per workgroup>            [8; 4 at P = 5, 6, 8]
+#   -DPMG_NW=<max waves per workgroup>            [8; 4 at P = 3, 5, 6, 8]
 #   -DPMG_WPS=<min waves per SIMD, P <= 4>  -DPMG_WPS_HI=<same, P >= 5>   [from NW; 1]
 #   -DPMG_GDEPTH=<G layers in flight>             [1]
 #   -DPMG_DLDS_FROM=<P from which the 1-D tables are re-read from LDS>     [9 = never]
