@@ -10,6 +10,9 @@ the eigenvalues its ``tqli`` routine (``:47-60``) returns for it, plus scipy's
 import importlib.util
 import json
 import os
+import sys
+
+sys.dont_write_bytecode = True  # the reference tree is read-only for us: no __pycache__ next to its file
 
 import numpy as np
 from scipy import linalg
