@@ -538,3 +538,31 @@ def test_flexible_pcg_with_krylov_coarse_solver(pm):
     h.operators[-1](x, y)
     pm.axpy(r, -1.0, y, h.rhs[-1])
     assert pm.norm(r) < 1e-7 * pm.norm(h.rhs[-1])  # the recurrence residual is honest
+
+
+def test_apply_parity_random_small_meshes(pm):
+    """Seeded sweep over odd little meshes (single cells, one-cell-thick slabs, sizes that leave
+    partial patches and partial wave items in every direction) and all degrees, with an arbitrary
+    split into the two cell lists and a random Dirichlet marker."""
+    from oracle import pmg_oracle as po
+
+    rng = np.random.default_rng(2024)
+    shapes = [(1, 1, 1), (1, 1, 9), (9, 1, 1), (2, 3, 1), (1, 5, 2), (3, 3, 3), (5, 2, 7), (4, 4, 9)]
+    for case in range(24):
+        P = int(rng.integers(1, 9))
+        n = shapes[case % len(shapes)] if P <= 4 else shapes[case % 6]
+        part = pm.BoxPartition(n, warp=twist)
+        lv = part.level(P)
+        bc = (rng.uniform(size=lv.ndofs) < 0.15).astype(np.int8)
+        kappa = rng.uniform(0.5, 2.0, part.ncells)
+        mask = rng.uniform(size=part.ncells) < 0.6
+        lcells = np.nonzero(mask)[0].astype(np.int32)
+        bcells = np.nonzero(~mask)[0].astype(np.int32)
+        layout = pm.Layout(lv.ndofs)
+        op = pm.MatFreeLaplacian(P, kappa, lv.dofmap, part.xgeom, part.geom_dofmap, lcells, bcells, bc, layout)
+        A = po.Laplacian(P, kappa, lv.dofmap, part.xgeom, part.geom_dofmap, bc)
+        u = rng.standard_normal(lv.ndofs)
+        x, y = _vec(pm, layout, u), pm.Vector(layout)
+        y.set(3.0)
+        op(x, y)
+        assert _relerr(y.data_copy(), A.apply(u)) < 1e-12, (case, P, n)
