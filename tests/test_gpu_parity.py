@@ -566,3 +566,24 @@ def test_apply_parity_random_small_meshes(pm):
         y.set(3.0)
         op(x, y)
         assert _relerr(y.data_copy(), A.apply(u)) < 1e-12, (case, P, n)
+
+
+@pytest.mark.parametrize("P,n", [(1, (8, 8, 16)), (2, (8, 8, 16)), (4, (4, 4, 16)), (6, (4, 4, 4))])
+def test_merged_and_coloured_launches_agree(pm, P, n, monkeypatch):
+    """The same operator built with the interior colours as separate launches (plain stores) and
+    merged into one launch (atomics): same result, and both equal the oracle."""
+    part, lv, layout, _, A = _single_level(pm, n, P, warped="twist")
+    u = np.random.default_rng(7).standard_normal(lv.ndofs)
+    x = _vec(pm, layout, u)
+    got = {}
+    for name, below in (("coloured", "0"), ("merged", "1000000000")):
+        monkeypatch.setenv("PMG_MERGE_BELOW", below)
+        op = pm.MatFreeLaplacian(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells, lv.bc_marker,
+                                 layout)
+        y = pm.Vector(layout)
+        y.set(1.0)
+        op(x, y)
+        got[name] = (y.data_copy(), op.launches_per_apply())
+    assert got["coloured"][1] > 1 and got["merged"][1] == 1
+    ref = A.apply(u)
+    assert _relerr(got["coloured"][0], ref) < 1e-12 and _relerr(got["merged"][0], ref) < 1e-12
