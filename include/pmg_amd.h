@@ -39,6 +39,7 @@ extern "C" {
 typedef void* pmg_stream; /* hipStream_t (0 = default stream) */
 
 typedef struct pmg_layout_s* pmg_layout;
+typedef struct pmg_comm_s* pmg_comm;
 typedef struct pmg_laplacian_s* pmg_laplacian;
 typedef struct pmg_chebyshev_s* pmg_chebyshev;
 typedef struct pmg_cg_s* pmg_cg;
@@ -99,6 +100,34 @@ int32_t pmg_layout_num_ghosts(pmg_layout l);
  * to pmg_layout_create.  Without it pmg_vec_norm(linf) fails on a layout that has an
  * allreduce_sum callback (several ranks), because a sum cannot stand in for a maximum. */
 int pmg_layout_set_allreduce_max(pmg_layout l, pmg_allreduce_fn allreduce_max);
+
+/* ---- native communicator: RCCL over xGMI, issued by the library -------------
+ * The alternative to the two callbacks above for one-process-per-GPU runs on one node: the
+ * library itself posts the neighbour exchange (one group of ncclSend/ncclRecv per scatter, on
+ * the communicator's own stream, ordered against the compute stream with events -- no host
+ * synchronisation, no callback) and sums the scalars of the reductions with ncclAllReduce on
+ * device memory.  This is the role of dolfinx's Scatterer + MPI in the reference
+ * (src/vector.hpp:94,203-206,215,350).  RCCL is bound at run time (librccl.so.1).
+ *
+ *   pmg_comm_unique_id : rank 0 obtains the 128-byte id (ncclGetUniqueId) and hands it to the
+ *                        other ranks by whatever means the caller has (a file, MPI_Bcast,
+ *                        torch.distributed.broadcast ...);
+ *   pmg_comm_create    : collective over all ranks (ncclCommInitRank) on the current device;
+ *   pmg_layout_set_comm: attaches the communicator and the neighbour list of the halo plan --
+ *                        neighbour i receives send_buffer[sum(send_counts[:i]) ...) and fills
+ *                        recv_buffer[sum(recv_counts[:i]) ...), i.e. the index lists given to
+ *                        pmg_layout_create are grouped by neighbour in this order.  Every rank
+ *                        of the communicator must call every scatter / reduction of a layout
+ *                        in the same order (they are collectives), also a rank with no
+ *                        neighbours.  The communicator must outlive the layout. */
+#define PMG_COMM_ID_BYTES 128
+int pmg_comm_unique_id(char* id /* [PMG_COMM_ID_BYTES] */);
+int pmg_comm_create(pmg_comm* out, int rank, int nranks, const char* id);
+int pmg_comm_destroy(pmg_comm comm);
+int pmg_comm_rank(pmg_comm comm);
+int pmg_comm_size(pmg_comm comm);
+int pmg_layout_set_comm(pmg_layout l, pmg_comm comm, int32_t n_neighbors, const int32_t* neighbor_ranks,
+                        const int32_t* send_counts, const int32_t* recv_counts);
 
 /* Vector::scatter_fwd_begin / scatter_fwd_end (src/vector.hpp:186-238): owner ->
  * ghost update of x; pack/unpack run on `stream` without host synchronisation. */
@@ -195,16 +224,28 @@ int pmg_laplacian_is_affine(pmg_laplacian op);
 int pmg_laplacian_set_geometry_mode(pmg_laplacian op, int mode);
 /* One operator application issues one stiffness-kernel launch per patch colour of the
  * interior cell list (8 on a structured box) plus one for the boundary list; on a small
- * level -- fewer patch dofs in the interior list than 2 M (degree <= 2) / 6 M (degree >= 3),
- * environment variable PMG_MERGE_BELOW overrides -- the colours are merged into one launch
- * that accumulates with atomics. */
+ * level -- fewer patch dofs in the interior list than 2 M (degree <= 2) / 6 M (degree >= 3) --
+ * the colours are merged into one launch that accumulates with atomics.
+ * pmg_set_merge_threshold overrides that limit for operators created afterwards (0: always
+ * coloured launches, a huge value: always merged, negative: the defaults above); process-wide,
+ * for tests and tuning. */
 int pmg_laplacian_launches_per_apply(pmg_laplacian op);
+int pmg_set_merge_threshold(long long patch_dofs);
 /* Dominant-kernel timing hook for bench.py: enqueue `reps` times every
  * stiffness-kernel launch of one operator application (no halo, no zero-fill)
  * bracketed by HIP events on `stream`; returns the mean milliseconds per launch
  * (= time per application / pmg_laplacian_launches_per_apply). */
 int pmg_laplacian_time_kernel(pmg_laplacian op, const double* in, double* out, int reps,
                               double* ms_per_launch, pmg_stream stream);
+
+/* In-situ timing of the same kernels where they run (inside a smoother, a V-cycle, a CG
+ * iteration): while profiling is on, every run of stiffness-kernel launches an operator
+ * application issues is bracketed by a pair of HIP events on the launch stream (a few
+ * microseconds of host time per application -- leave it off in timed loops).
+ * pmg_laplacian_read_profile waits for the recorded events, returns the summed milliseconds
+ * and the number of stiffness launches they cover, and resets the record. */
+int pmg_laplacian_set_profiling(pmg_laplacian op, int flag);
+int pmg_laplacian_read_profile(pmg_laplacian op, double* total_ms, long long* launches);
 
 /* ---- Chebyshev smoother (acc::Chebyshev, src/chebyshev.hpp:19-106) -------- */
 int pmg_chebyshev_create(pmg_chebyshev* out, pmg_layout layout, double eig_min, double eig_max);
@@ -285,6 +326,13 @@ int pmg_multigrid_set_interpolators(pmg_multigrid mg, const pmg_interpolator* in
  * BoomerAMG, third-party arithmetic that is out of scope here: the library's CG is
  * Jacobi-preconditioned.  `coarse` must live on the coarsest layout and outlive `mg`. */
 int pmg_multigrid_set_coarse_solver(pmg_multigrid mg, pmg_cg coarse);
+/* The same hook for ANY coarse solver -- the reference's CoarseSolver concept is "a type with
+ * solve(Vector& x, Vector& b)" (src/amg.hpp:67, called at src/pmg.hpp:106-107): `solve` receives
+ * the coarsest-level solution (zeroed beforehand) and right-hand side as device arrays of
+ * size_local + num_ghosts doubles and the stream the cycle runs on; it returns 0 on success.
+ * NULL restores the smoother.  (pmg_amg below is the library's own such solver.) */
+typedef int (*pmg_coarse_solve_fn)(void* user, double* x, double* b, pmg_stream stream);
+int pmg_multigrid_set_coarse_callback(pmg_multigrid mg, pmg_coarse_solve_fn solve, void* user);
 /* apply(x = rhs, y = initial guess in / result out, verbose), :56-155.  If
  * rnorm is non-NULL the final residual norm ||b - A y|| is computed (the
  * reference prints it when verbose, :147-150) -- this costs one extra apply and a

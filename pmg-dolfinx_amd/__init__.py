@@ -8,9 +8,9 @@ from . import _lib  # noqa: F401
 from .cg import CGSolver  # noqa: F401
 from .chebyshev import Chebyshev  # noqa: F401
 from .interpolate import Interpolator  # noqa: F401
-from .laplacian import MatFreeLaplacian  # noqa: F401
+from .laplacian import MatFreeLaplacian, set_merge_threshold  # noqa: F401
 from .mesh import BoxPartition, default_proc_dims  # noqa: F401
 from .pmg import MultigridPreconditioner  # noqa: F401
 from .problem import PoissonHierarchy, make_layout  # noqa: F401
-from .vector import (Layout, Vector, axpy, copy, inner_product, norm, pointwise_mult, scale,  # noqa: F401
+from .vector import (Layout, RcclComm, TorchComm, Vector, axpy, copy, inner_product, norm, pointwise_mult, scale,  # noqa: F401
                      squared_norm)

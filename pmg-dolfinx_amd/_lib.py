@@ -19,6 +19,7 @@ vp = C.c_void_p
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int, vp)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, c_dp, C.c_int)
+COARSE_FN = C.CFUNCTYPE(C.c_int, vp, vp, vp, vp)
 
 
 class PmgError(RuntimeError):
@@ -41,6 +42,12 @@ _SIGS = {
     "pmg_layout_size_local": (C.c_int32, [vp]),
     "pmg_layout_num_ghosts": (C.c_int32, [vp]),
     "pmg_layout_set_allreduce_max": (C.c_int, [vp, ALLREDUCE_FN]),
+    "pmg_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "pmg_comm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p]),
+    "pmg_comm_destroy": (C.c_int, [vp]),
+    "pmg_comm_rank": (C.c_int, [vp]),
+    "pmg_comm_size": (C.c_int, [vp]),
+    "pmg_layout_set_comm": (C.c_int, [vp, vp, C.c_int32, c_ip, c_ip, c_ip]),
     "pmg_scatter_fwd_begin": (C.c_int, [vp, vp, vp]),
     "pmg_scatter_fwd_end": (C.c_int, [vp, vp, vp]),
     "pmg_scatter_rev_begin": (C.c_int, [vp, vp, vp]),
@@ -73,6 +80,9 @@ _SIGS = {
     "pmg_laplacian_is_affine": (C.c_int, [vp]),
     "pmg_laplacian_set_geometry_mode": (C.c_int, [vp, C.c_int]),
     "pmg_laplacian_launches_per_apply": (C.c_int, [vp]),
+    "pmg_set_merge_threshold": (C.c_int, [C.c_longlong]),
+    "pmg_laplacian_set_profiling": (C.c_int, [vp, C.c_int]),
+    "pmg_laplacian_read_profile": (C.c_int, [vp, c_dp, C.POINTER(C.c_longlong)]),
     "pmg_laplacian_time_kernel": (C.c_int, [vp, vp, vp, C.c_int, c_dp, vp]),
     "pmg_chebyshev_create": (C.c_int, [C.POINTER(vp), vp, C.c_double, C.c_double]),
     "pmg_chebyshev_destroy": (C.c_int, [vp]),
@@ -106,12 +116,13 @@ _SIGS = {
     "pmg_multigrid_set_solvers": (C.c_int, [vp, C.POINTER(vp)]),
     "pmg_multigrid_set_interpolators": (C.c_int, [vp, C.POINTER(vp)]),
     "pmg_multigrid_set_coarse_solver": (C.c_int, [vp, vp]),
+    "pmg_multigrid_set_coarse_callback": (C.c_int, [vp, COARSE_FN, vp]),
     "pmg_multigrid_apply": (C.c_int, [vp, vp, vp, c_dp, vp]),
     "pmg_multigrid_apply_counts": (C.c_int, [vp, C.POINTER(C.c_int), C.c_int]),
 }
 
 # functions whose int return value is a count, not a status
-_COUNT_FUNCS = {"pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
+_COUNT_FUNCS = {"pmg_comm_rank", "pmg_comm_size", "pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
                 "pmg_laplacian_degree", "pmg_laplacian_launches_per_apply", "pmg_laplacian_is_affine"}
 
 _lib = None

@@ -79,9 +79,16 @@ struct HandleGuard
   }
 };
 
+struct pmg_comm_s;
+
 struct pmg_layout_s
 {
   int32_t size_local = 0, num_ghosts = 0, n_send = 0, n_recv = 0;
+  // native communicator (comm.hip): when set, the exchange and the reductions are issued by the
+  // library on RCCL and the callbacks below are not used
+  pmg_comm_s* comm = nullptr;
+  std::vector<int32_t> nb_rank, nb_send, nb_recv; // neighbour ranks and per-neighbour counts
+  hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
   const int32_t* send_idx = nullptr;
   const int32_t* recv_idx = nullptr;
   double* send_buf = nullptr;
@@ -91,8 +98,9 @@ struct pmg_layout_s
   pmg_allreduce_fn allreduce_max = nullptr;
   void* user = nullptr;
   // reduction scratch (owned)
-  double* d_partials = nullptr; // [2 * RED_BLOCKS]
-  double* h_result = nullptr;   // pinned, [4]
+  double* d_partials = nullptr; // [RED_BLOCKS] block partials + [RED_SLOTS] results
+  double* h_result = nullptr;   // pinned, [RED_SLOTS]
+  bool multi_rank() const { return comm != nullptr || allreduce != nullptr; }
   int32_t total() const { return size_local + num_ghosts; }
 };
 
@@ -100,9 +108,34 @@ namespace pmg
 {
 constexpr int RED_BLOCKS = 1024;
 constexpr int RED_THREADS = 256;
+constexpr int RED_SLOTS = 8;
+
+// comm.hip -- native (RCCL) exchange and reductions of a layout that has a communicator
+int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s);
+int comm_exchange_end(pmg_layout l, hipStream_t s);
+int comm_allreduce(pmg_layout l, double* d_values, int n, bool max, hipStream_t s);
+
+// Profiling ranges (roctx, bound at run time; no-ops when libroctx64 is absent).  The reference
+// annotates each CG iteration (src/amd_gpu.hpp:236-252, src/cg.hpp:174,219); here every phase of
+// the V-cycle carries a range as well, so a rocprofv3 --marker-trace reads like the algorithm.
+void range_push(const char* name);
+void range_pop();
+struct Range
+{
+  explicit Range(const char* name) { range_push(name); }
+  Range(const Range&) = delete;
+  Range& operator=(const Range&) = delete;
+  ~Range() { range_pop(); }
+};
 
 // vector.hip -- stream-ordered building blocks used by the solvers
-int dot_async(pmg_layout l, const double* a, const double* b, double* d_out, hipStream_t s);
+// local dot of the owned entries into the result slot `slot` of the layout (device)
+int dot_async(pmg_layout l, const double* a, const double* b, int slot, hipStream_t s);
+double* red_slot(pmg_layout l, int slot);
+// sum / maximise the slots [slot, slot + n) over the ranks; the device slots then hold the global values
+int reduce_slots_async(pmg_layout l, int slot, int n, bool max, hipStream_t s);
+// ... and bring them to the host: the one host synchronisation of a reduction
+int fetch_slots(pmg_layout l, int slot, int n, double* host_out, hipStream_t s);
 int dot_host(pmg_layout l, const double* a, const double* b, double* result, hipStream_t s);
 void launch_axpy(int n, double* r, double alpha, const double* x, const double* y, hipStream_t s);
 void launch_pointwise(int n, double* w, const double* x, const double* y, hipStream_t s);
@@ -115,7 +148,12 @@ void launch_add(int n, double* x, const double* z, hipStream_t s);
 void launch_cheb_last(int n, double* x, double* r, const double* z, const double* q, bool assign,
                       hipStream_t s);
 void launch_mask_bc(int n, double* b, const int8_t* bc, hipStream_t s);
-// CG fused passes (src/cg.hpp:160-211)
+// CG fused passes (src/cg.hpp:160-211); alpha = rnorm / *d_py and beta = (*d_new - *d_sub) / rnorm are
+// formed on the device from the reduced scalars, so no host round trip sits between the kernels
 void launch_cg_update(int n, double* x, double* r, double* y, const double* p, const double* dinv,
-                      double alpha, hipStream_t s);
+                      double rnorm, const double* d_py, hipStream_t s);
+void launch_cg_update2(int n, double* x, double* r, const double* p, const double* y, double rnorm,
+                       const double* d_py, hipStream_t s);
+void launch_cg_direction(int n, double* p, const double* y, double rnorm, const double* d_new,
+                         const double* d_sub, hipStream_t s);
 } // namespace pmg

@@ -77,6 +77,11 @@ struct pmg_laplacian_s
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   long long launches = 0; // full operator applications' kernel launches since creation
   long long applies = 0;
+  // in-situ timing of the stiffness launches (pmg_laplacian_set_profiling)
+  bool profiling = false;
+  std::vector<hipEvent_t> prof_events; // pairs: before / after a run of launches
+  size_t prof_used = 0;
+  long long prof_launches = 0;
 };
 
 namespace
@@ -953,6 +958,19 @@ int launch_stiffness(pmg_laplacian op, const double* x, double* y, int first, in
 // launches [l0, l1) of the plan, in stream order
 int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, hipStream_t s)
 {
+  const bool prof = op->profiling && l1 > l0;
+  if (prof)
+  {
+    if (op->prof_used + 2 > op->prof_events.size())
+    {
+      hipEvent_t a, b;
+      PMG_HIP(hipEventCreate(&a));
+      op->prof_events.push_back(a);
+      PMG_HIP(hipEventCreate(&b));
+      op->prof_events.push_back(b);
+    }
+    PMG_HIP(hipEventRecord(op->prof_events[op->prof_used], s));
+  }
   for (int l = l0; l < l1; ++l)
   {
     const int first = op->launch_first[l], count = op->launch_count[l];
@@ -988,6 +1006,12 @@ int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, h
     }
   }
   PMG_HIP(hipGetLastError());
+  if (prof)
+  {
+    PMG_HIP(hipEventRecord(op->prof_events[op->prof_used + 1], s));
+    op->prof_used += 2;
+    op->prof_launches += l1 - l0;
+  }
   return PMG_OK;
 }
 
@@ -1289,6 +1313,8 @@ extern "C" int pmg_laplacian_destroy(pmg_laplacian op)
   (void)hipFree(op->lmap_id);
   (void)hipFree(op->lmaps);
   (void)hipFree(op->diag_inv);
+  for (hipEvent_t e : op->prof_events)
+    (void)hipEventDestroy(e);
   if (op->ev0)
     (void)hipEventDestroy(op->ev0);
   if (op->ev1)
@@ -1408,6 +1434,33 @@ extern "C" int pmg_laplacian_time_kernel(pmg_laplacian op, const double* in, dou
   float ms = 0.f;
   PMG_HIP(hipEventElapsedTime(&ms, op->ev0, op->ev1));
   *ms_per_launch = (double)ms / reps / nl;
+  return PMG_OK;
+}
+
+extern "C" int pmg_laplacian_set_profiling(pmg_laplacian op, int flag)
+{
+  PMG_REQUIRE(op, "pmg_laplacian_set_profiling: NULL argument");
+  op->profiling = flag != 0;
+  op->prof_used = 0;
+  op->prof_launches = 0;
+  return PMG_OK;
+}
+
+extern "C" int pmg_laplacian_read_profile(pmg_laplacian op, double* total_ms, long long* launches)
+{
+  PMG_REQUIRE(op && total_ms && launches, "pmg_laplacian_read_profile: NULL argument");
+  double sum = 0.0;
+  for (size_t i = 0; i + 1 < op->prof_used; i += 2)
+  {
+    PMG_HIP(hipEventSynchronize(op->prof_events[i + 1]));
+    float ms = 0.f;
+    PMG_HIP(hipEventElapsedTime(&ms, op->prof_events[i], op->prof_events[i + 1]));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = op->prof_launches;
+  op->prof_used = 0;
+  op->prof_launches = 0;
   return PMG_OK;
 }
 

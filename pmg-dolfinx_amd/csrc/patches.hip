@@ -4,12 +4,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <cstdlib>
 #include <map>
 #include <numeric>
 
 namespace pmg
 {
+long long g_merge_below = -1; // pmg_set_merge_threshold; < 0 = the measured defaults
 namespace
 {
 // Rank transform of one coordinate: cluster values closer than tol, return the
@@ -342,9 +342,7 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
     const int nl = ncolours[0];
     const int32_t bfirst = nl < nlaunch ? plan.launch_first[nl] : np;
     const long long interior_pdofs = plan.poff[bfirst];
-    long long merge_below = (P <= 2 ? 2 : 6) << 20;
-    if (const char* e = getenv("PMG_MERGE_BELOW"))
-      merge_below = atoll(e);
+    const long long merge_below = g_merge_below >= 0 ? g_merge_below : (long long)(P <= 2 ? 2 : 6) << 20;
     const bool merge_interior = nl > 1 && interior_pdofs <= merge_below;
     std::vector<int32_t> lf, lc;
     if (merge_interior)
@@ -377,3 +375,9 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
   return PMG_OK;
 }
 } // namespace pmg
+
+extern "C" int pmg_set_merge_threshold(long long patch_dofs)
+{
+  pmg::g_merge_below = patch_dofs;
+  return PMG_OK;
+}

@@ -61,7 +61,10 @@ struct pmg_multigrid_s
   std::vector<pmg_interpolator> interps;
   std::vector<double*> u, b; // per level (finest level uses the caller's vectors)
   std::vector<int> counts;
-  pmg_cg coarse = nullptr;   // optional Krylov coarse solver (src/pmg.hpp:106-107)
+  // optional coarse solver (src/pmg.hpp:106-107): the library's CG, or any solve(x, b) of the caller
+  pmg_cg coarse = nullptr;
+  pmg_coarse_solve_fn coarse_fn = nullptr;
+  void* coarse_user = nullptr;
 };
 
 namespace
@@ -135,38 +138,56 @@ int mg_apply(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStr
     before[i] = laplacian_launches(mg->ops[i]);
   // u[L-1] = y, b[L-1] = rhs (:65,68) -- used in place; u[i<L-1] = 0 (:63-64) is
   // folded into the smoothers' x_zero path.
+  Range cycle("pmg:vcycle");
   mg->u[L - 1] = y;
   for (int i = L - 1; i > 0; --i)
   {
     const double* bi = (i == L - 1) ? rhs : mg->b[i];
     const bool zero = (i == L - 1) ? y_zero : true;
-    PMG_TRY(cheb_solve(mg->smoothers[i], mg->ops[i], mg->u[i], bi, true, zero, s)); // :83-87
+    {
+      Range rg("pmg:pre_smooth");
+      PMG_TRY(cheb_solve(mg->smoothers[i], mg->ops[i], mg->u[i], bi, true, zero, s)); // :83-87
+    }
+    Range rg("pmg:restrict");
     PMG_TRY(interp_restrict(mg->interps[i - 1], mg->smoothers[i]->r, mg->b[i - 1], s)); // :92
   }
   if (L > 1)
     launch_mask_bc(mg->layouts[0]->size_local, mg->b[0], mg->bc0, s); // :100-103
   {
+    Range rg("pmg:coarse_solve");
     const double* b0 = (L == 1) ? rhs : mg->b[0];
     const bool zero = (L == 1) ? y_zero : true;
-    if (mg->coarse && L > 1) // :106-107, KSP-style: zero initial guess
+    if ((mg->coarse || mg->coarse_fn) && L > 1) // :106-107, KSP-style: zero initial guess
     {
       PMG_HIP(hipMemsetAsync(mg->u[0], 0, sizeof(double) * mg->layouts[0]->total(), s));
-      int its = 0;
-      PMG_TRY(pmg_cg_solve(mg->coarse, mg->ops[0], mg->u[0], b0, nullptr, &its, (pmg_stream)s));
+      if (mg->coarse_fn)
+      {
+        if (mg->coarse_fn(mg->coarse_user, mg->u[0], mg->b[0], (pmg_stream)s) != 0)
+          return fail(PMG_ERR_INVALID, "the coarse-solver callback failed");
+      }
+      else
+      {
+        int its = 0;
+        PMG_TRY(pmg_cg_solve(mg->coarse, mg->ops[0], mg->u[0], b0, nullptr, &its, (pmg_stream)s));
+      }
     }
     else
       PMG_TRY(cheb_solve(mg->smoothers[0], mg->ops[0], mg->u[0], b0, false, zero, s)); // :109
   }
   for (int i = 0; i < L - 1; ++i)
   {
-    if (interp_is_patched(mg->interps[i]))
-      PMG_TRY(interp_prolong_add(mg->interps[i], mg->u[i], mg->u[i + 1], s)); // :123 + :129 in one pass
-    else
     {
-      double* du = mg->smoothers[i + 1]->q;                            // work vector as du
-      PMG_TRY(interp_prolong(mg->interps[i], mg->u[i], du, s));        // :123
-      launch_add(mg->layouts[i + 1]->size_local, mg->u[i + 1], du, s); // :129
+      Range rg("pmg:prolong");
+      if (interp_is_patched(mg->interps[i]))
+        PMG_TRY(interp_prolong_add(mg->interps[i], mg->u[i], mg->u[i + 1], s)); // :123 + :129 in one pass
+      else
+      {
+        double* du = mg->smoothers[i + 1]->q;                            // work vector as du
+        PMG_TRY(interp_prolong(mg->interps[i], mg->u[i], du, s));        // :123
+        launch_add(mg->layouts[i + 1]->size_local, mg->u[i + 1], du, s); // :129
+      }
     }
+    Range rg("pmg:post_smooth");
     const double* bi = (i + 1 == L - 1) ? rhs : mg->b[i + 1];
     PMG_TRY(cheb_solve(mg->smoothers[i + 1], mg->ops[i + 1], mg->u[i + 1], bi, false, false, s)); // :138
   }
@@ -284,11 +305,8 @@ extern "C" int pmg_cg_solve(pmg_cg cg, pmg_laplacian A, double* x, const double*
 
   auto precondition = [&](double* out_z, const double* in_r) -> int
   {
-    if (precond)
-    {
-      PMG_HIP(hipMemsetAsync(out_z, 0, sizeof(double) * l->total(), s));
+    if (precond) // zero initial guess: folded into the smoothers' x_zero path, no memset of out_z
       return mg_apply(precond, in_r, out_z, true, s);
-    }
     launch_pointwise(n, out_z, in_r, dinv, s); // :161,192
     return PMG_OK;
   };
@@ -307,37 +325,45 @@ extern "C" int pmg_cg_solve(pmg_cg cg, pmg_laplacian A, double* x, const double*
   PMG_TRY(dot_host(l, p, r, &rnorm0, s)); // :163
   double rnorm = rnorm0;
   const double rtol2 = cg->rtol * cg->rtol;
+  // The loop keeps its scalars on the device: p.y, r.z (and r.z_old) are reduced there (one
+  // ncclAllReduce each when the layout has a communicator), alpha and beta are formed inside the
+  // update kernels, and the host reads the values ONCE per iteration, at its end, for the stopping
+  // test and the Lanczos record -- the reference takes two blocking MPI_Allreduce per iteration
+  // (src/cg.hpp:182,195).  Result slots: 1 = p.y, 2 = r.z, 3 = r.z_old.
   int k = 0;
   while (k < cg->max_iter)
   {
     ++k;
+    Range range("pmg:cg_iteration"); // src/cg.hpp:174,219
     PMG_TRY(laplacian_apply(A, p, y, s)); // :179
-    double py;
-    PMG_TRY(dot_host(l, p, y, &py, s));
-    const double alpha = rnorm / py; // :182
+    PMG_TRY(dot_async(l, p, y, 1, s));
+    PMG_TRY(reduce_slots_async(l, 1, 1, false, s));
     if (precond)
     {
-      launch_axpy(n, x, alpha, p, x, s);  // :186
-      launch_axpy(n, r, -alpha, y, r, s); // :189
+      launch_cg_update2(n, x, r, p, y, rnorm, red_slot(l, 1), s); // :182-189
       PMG_TRY(precondition(y, r));
     }
     else
-      launch_cg_update(n, x, r, y, p, dinv, alpha, s); // :186-192 fused
-    double rnorm_new;
-    PMG_TRY(dot_host(l, r, y, &rnorm_new, s)); // :195
-    double beta = rnorm_new / rnorm;
+      launch_cg_update(n, x, r, y, p, dinv, rnorm, red_slot(l, 1), s); // :182-192 fused
+    PMG_TRY(dot_async(l, r, y, 2, s)); // :195
     if (flex)
-    {
-      double rz_old;
-      PMG_TRY(dot_host(l, r, cg->zold, &rz_old, s));
-      beta = (rnorm_new - rz_old) / rnorm; // r_new . (z_new - z_old) / (r_old . z_old)
+      PMG_TRY(dot_async(l, r, cg->zold, 3, s));
+    PMG_TRY(reduce_slots_async(l, 2, flex ? 2 : 1, false, s));
+    // :196,211 -- issued before the stopping test is known; if the loop ends here the new
+    // direction is simply never used
+    launch_cg_direction(n, p, y, rnorm, red_slot(l, 2), flex ? red_slot(l, 3) : nullptr, s);
+    if (flex)
       PMG_HIP(hipMemcpyAsync(cg->zold, y, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-    }
+    double v[3] = {0, 0, 0};
+    PMG_TRY(fetch_slots(l, 1, flex ? 3 : 2, v, s)); // the iteration's one host synchronisation
+    const double alpha = rnorm / v[0]; // :182
+    const double rnorm_new = v[1];
+    // flexible: r_new . (z_new - z_old) / (r_old . z_old)
+    const double beta = (flex ? rnorm_new - v[2] : rnorm_new) / rnorm;
     rnorm = rnorm_new;
     if (rnorm / rnorm0 < rtol2) // :206
       break;
-    launch_axpy(n, p, beta, p, y, s); // :211
-    if (cg->store)                    // :213-218
+    if (cg->store) // :213-218
     {
       cg->alphas.push_back(alpha);
       cg->betas.push_back(beta);
@@ -437,6 +463,17 @@ extern "C" int pmg_multigrid_set_coarse_solver(pmg_multigrid mg, pmg_cg coarse)
   PMG_REQUIRE(!coarse || coarse->layout == mg->layouts[0],
               "pmg_multigrid_set_coarse_solver: the solver is not on the coarsest layout");
   mg->coarse = coarse;
+  mg->coarse_fn = nullptr;
+  return PMG_OK;
+}
+
+extern "C" int pmg_multigrid_set_coarse_callback(pmg_multigrid mg, pmg_coarse_solve_fn solve, void* user)
+{
+  PMG_REQUIRE(mg, "pmg_multigrid_set_coarse_callback: NULL argument");
+  mg->coarse_fn = solve;
+  mg->coarse_user = user;
+  if (solve)
+    mg->coarse = nullptr;
   return PMG_OK;
 }
 

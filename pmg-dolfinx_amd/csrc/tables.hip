@@ -5,10 +5,50 @@
 #include "common.hpp"
 
 #include <cmath>
+#include <dlfcn.h>
 
 namespace pmg
 {
 thread_local std::string g_last_error;
+
+// roctx, bound at run time (an optional dependency: without libroctx64 the ranges are no-ops)
+namespace
+{
+struct Roctx
+{
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx()
+  {
+    void* h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_NOLOAD);
+    const char* names[] = {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so.4"};
+    for (int i = 0; !h && i < 3; ++i)
+      h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!h)
+      return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop)
+      push = nullptr, pop = nullptr;
+  }
+};
+Roctx& roctx()
+{
+  static Roctx r;
+  return r;
+}
+} // namespace
+
+void range_push(const char* name)
+{
+  if (roctx().push)
+    roctx().push(name);
+}
+void range_pop()
+{
+  if (roctx().pop)
+    roctx().pop();
+}
 
 int fail(int code, const char* fmt, ...)
 {

@@ -306,15 +306,17 @@ struct MaskBcF
   }
 };
 struct CgUpdateF
-{ // x += alpha p ; r -= alpha y ; y = dinv r   (src/cg.hpp:186-192)
+{ // x += alpha p ; r -= alpha y ; y = dinv r   (src/cg.hpp:186-192), alpha = rnorm / *d_py (:182)
   double* x;
   double* r;
   double* y;
   const double* p;
   const double* dinv;
-  double alpha;
+  double rnorm;
+  const double* d_py;
   __device__ void pair(int i) const
   {
+    const double alpha = rnorm / *d_py;
     double2 vx = D2(x)[i], vr = D2(r)[i], vy = D2(y)[i];
     double2 vp = CD2(p)[i], vd = CD2(dinv)[i];
     vx.x += alpha * vp.x;
@@ -327,10 +329,52 @@ struct CgUpdateF
   }
   __device__ void one(int i) const
   {
+    const double alpha = rnorm / *d_py;
     x[i] += alpha * p[i];
     double vr = r[i] - alpha * y[i];
     r[i] = vr;
     y[i] = dinv[i] * vr;
+  }
+};
+struct CgUpdate2F
+{ // x += alpha p ; r -= alpha y   (src/cg.hpp:186-189) when the preconditioner is not the diagonal
+  double* x;
+  double* r;
+  const double* p;
+  const double* y;
+  double rnorm;
+  const double* d_py;
+  __device__ void pair(int i) const
+  {
+    const double alpha = rnorm / *d_py;
+    double2 vx = D2(x)[i], vr = D2(r)[i], vy = CD2(y)[i], vp = CD2(p)[i];
+    D2(x)[i] = make_double2(vx.x + alpha * vp.x, vx.y + alpha * vp.y);
+    D2(r)[i] = make_double2(vr.x - alpha * vy.x, vr.y - alpha * vy.y);
+  }
+  __device__ void one(int i) const
+  {
+    const double alpha = rnorm / *d_py;
+    x[i] += alpha * p[i];
+    r[i] -= alpha * y[i];
+  }
+};
+struct CgDirectionF
+{ // p = beta p + y   (src/cg.hpp:196,211), beta = (*d_new - *d_sub) / rnorm (d_sub: flexible variant)
+  double* p;
+  const double* y;
+  double rnorm;
+  const double* d_new;
+  const double* d_sub;
+  __device__ void pair(int i) const
+  {
+    const double beta = (*d_new - (d_sub ? *d_sub : 0.0)) / rnorm;
+    double2 vp = D2(p)[i], vy = CD2(y)[i];
+    D2(p)[i] = make_double2(beta * vp.x + vy.x, beta * vp.y + vy.y);
+  }
+  __device__ void one(int i) const
+  {
+    const double beta = (*d_new - (d_sub ? *d_sub : 0.0)) / rnorm;
+    p[i] = beta * p[i] + y[i];
   }
 };
 
@@ -478,41 +522,78 @@ void launch_mask_bc(int n, double* b, const int8_t* bc, hipStream_t s)
   ew_launch(n, true, MaskBcF{b, bc}, s);
 }
 void launch_cg_update(int n, double* x, double* r, double* y, const double* p, const double* dinv,
-                      double alpha, hipStream_t s)
+                      double rnorm, const double* d_py, hipStream_t s)
 {
   bool v = aligned16(x) && aligned16(r) && aligned16(y) && aligned16(p) && aligned16(dinv);
-  ew_launch(n, v, CgUpdateF{x, r, y, p, dinv, alpha}, s);
+  ew_launch(n, v, CgUpdateF{x, r, y, p, dinv, rnorm, d_py}, s);
+}
+void launch_cg_update2(int n, double* x, double* r, const double* p, const double* y, double rnorm,
+                       const double* d_py, hipStream_t s)
+{
+  bool v = aligned16(x) && aligned16(r) && aligned16(y) && aligned16(p);
+  ew_launch(n, v, CgUpdate2F{x, r, p, y, rnorm, d_py}, s);
+}
+void launch_cg_direction(int n, double* p, const double* y, double rnorm, const double* d_new,
+                         const double* d_sub, hipStream_t s)
+{
+  ew_launch(n, aligned16(p) && aligned16(y), CgDirectionF{p, y, rnorm, d_new, d_sub}, s);
 }
 
-// local (this rank) dot of the owned entries -> d_out[0], stream-ordered
-int dot_async(pmg_layout l, const double* a, const double* b, double* d_out, hipStream_t s)
+double* red_slot(pmg_layout l, int slot) { return l->d_partials + RED_BLOCKS + slot; }
+
+// local (this rank) dot of the owned entries -> result slot, stream-ordered
+int dot_async(pmg_layout l, const double* a, const double* b, int slot, hipStream_t s)
 {
+  PMG_REQUIRE(slot >= 0 && slot < RED_SLOTS, "dot_async: bad slot");
   int n = l->size_local;
   int nb = ew_blocks((n + 1) / 2);
   if (nb > RED_BLOCKS)
     nb = RED_BLOCKS;
   int vec = aligned16(a) && aligned16(b);
   dot_partial_kernel<<<nb, RED_THREADS, 0, s>>>(n, a, b, l->d_partials, vec);
-  fold_kernel<false><<<1, RED_THREADS, 0, s>>>(nb, l->d_partials, d_out);
+  fold_kernel<false><<<1, RED_THREADS, 0, s>>>(nb, l->d_partials, red_slot(l, slot));
   PMG_HIP(hipGetLastError());
   return PMG_OK;
 }
 
-// inner_product of src/vector.hpp:334-352: local dot, host value, all-reduce
+// Sum (or maximise) the result slots [slot, slot + n) over the ranks; afterwards the DEVICE slots
+// hold the global values, so kernels may consume them without a host round trip.  With a
+// communicator this is one stream-ordered ncclAllReduce; with the caller's callback (MPI) the
+// values travel through the host, which costs a stream synchronisation.
+int reduce_slots_async(pmg_layout l, int slot, int n, bool max, hipStream_t s)
+{
+  PMG_REQUIRE(slot >= 0 && n >= 1 && slot + n <= RED_SLOTS, "reduce_slots_async: bad slot range");
+  if (l->comm)
+    return comm_allreduce(l, red_slot(l, slot), n, max, s);
+  pmg_allreduce_fn fn = max ? l->allreduce_max : l->allreduce;
+  if (!fn)
+    return PMG_OK; // single rank
+  PMG_HIP(hipMemcpyAsync(l->h_result, red_slot(l, slot), sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  PMG_HIP(hipStreamSynchronize(s));
+  if (fn(l->user, l->h_result, n) != 0)
+    return fail(PMG_ERR_INVALID, "allreduce callback failed");
+  PMG_HIP(hipMemcpyAsync(red_slot(l, slot), l->h_result, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  PMG_HIP(hipStreamSynchronize(s)); // h_result is reused by the next reduction
+  return PMG_OK;
+}
+
+// ... and bring them to the host: the one host synchronisation of a reduction
+int fetch_slots(pmg_layout l, int slot, int n, double* host_out, hipStream_t s)
+{
+  PMG_REQUIRE(slot >= 0 && n >= 1 && slot + n <= RED_SLOTS, "fetch_slots: bad slot range");
+  PMG_HIP(hipMemcpyAsync(l->h_result, red_slot(l, slot), sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  PMG_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < n; ++i)
+    host_out[i] = l->h_result[i];
+  return PMG_OK;
+}
+
+// inner_product of src/vector.hpp:334-352: local dot, all-reduce, host value
 int dot_host(pmg_layout l, const double* a, const double* b, double* result, hipStream_t s)
 {
-  PMG_TRY(dot_async(l, a, b, l->d_partials + RED_BLOCKS, s));
-  PMG_HIP(hipMemcpyAsync(l->h_result, l->d_partials + RED_BLOCKS, sizeof(double),
-                         hipMemcpyDeviceToHost, s));
-  PMG_HIP(hipStreamSynchronize(s));
-  double v = l->h_result[0];
-  if (l->allreduce)
-  {
-    if (l->allreduce(l->user, &v, 1) != 0)
-      return fail(PMG_ERR_INVALID, "allreduce callback failed");
-  }
-  *result = v;
-  return PMG_OK;
+  PMG_TRY(dot_async(l, a, b, 0, s));
+  PMG_TRY(reduce_slots_async(l, 0, 1, false, s));
+  return fetch_slots(l, 0, 1, result, s);
 }
 } // namespace pmg
 
@@ -532,8 +613,8 @@ extern "C" int pmg_layout_create(pmg_layout* out, int32_t size_local, int32_t nu
               "pmg_layout_create: send arrays missing");
   PMG_REQUIRE(n_recv == 0 || (recv_indices && recv_buffer),
               "pmg_layout_create: recv arrays missing");
-  PMG_REQUIRE((n_send == 0 && n_recv == 0) || exchange,
-              "pmg_layout_create: neighbours given but no exchange callback");
+  // (a layout with neighbours needs an exchange: the callback here, or pmg_layout_set_comm later;
+  // the scatter calls check)
   // with a callback every scatter calls it (it is a collective on the caller's
   // side), even when this rank shares no dof with anybody
   auto* l = new pmg_layout_s;
@@ -548,9 +629,9 @@ extern "C" int pmg_layout_create(pmg_layout* out, int32_t size_local, int32_t nu
   l->exchange = exchange;
   l->allreduce = allreduce_sum;
   l->user = user;
-  hipError_t e = hipMalloc(&l->d_partials, sizeof(double) * (RED_BLOCKS + 8));
+  hipError_t e = hipMalloc(&l->d_partials, sizeof(double) * (RED_BLOCKS + RED_SLOTS));
   if (e == hipSuccess)
-    e = hipHostMalloc(&l->h_result, sizeof(double) * 4, hipHostMallocDefault);
+    e = hipHostMalloc(&l->h_result, sizeof(double) * RED_SLOTS, hipHostMallocDefault);
   if (e != hipSuccess)
   {
     delete l;
@@ -566,6 +647,10 @@ extern "C" int pmg_layout_destroy(pmg_layout l)
     return PMG_OK;
   (void)hipFree(l->d_partials);
   (void)hipHostFree(l->h_result);
+  if (l->ev_packed)
+    (void)hipEventDestroy(l->ev_packed);
+  if (l->ev_arrived)
+    (void)hipEventDestroy(l->ev_arrived);
   delete l;
   return PMG_OK;
 }
@@ -583,12 +668,18 @@ extern "C" int pmg_layout_set_allreduce_max(pmg_layout l, pmg_allreduce_fn allre
 extern "C" int pmg_scatter_fwd_begin(pmg_layout l, const double* x, pmg_stream stream)
 {
   PMG_REQUIRE(l && x, "pmg_scatter_fwd_begin: NULL argument");
-  if (!l->exchange)
+  if (!l->comm && !l->exchange)
+  {
+    PMG_REQUIRE(l->n_send == 0 && l->n_recv == 0,
+                "scatter: the layout has neighbours but neither a communicator nor an exchange callback");
     return PMG_OK; // single rank
+  }
   if (l->n_send > 0)
     pack_kernel<<<ew_blocks(l->n_send), EW_THREADS, 0, S(stream)>>>(l->n_send, l->send_idx, x,
                                                                     l->send_buf);
   PMG_HIP(hipGetLastError());
+  if (l->comm)
+    return comm_exchange_begin(l, false, S(stream));
   if (l->exchange(l->user, 0, stream) != 0)
     return fail(PMG_ERR_INVALID, "exchange callback (begin) failed");
   return PMG_OK;
@@ -598,9 +689,11 @@ extern "C" int pmg_scatter_fwd_begin(pmg_layout l, const double* x, pmg_stream s
 extern "C" int pmg_scatter_fwd_end(pmg_layout l, double* x, pmg_stream stream)
 {
   PMG_REQUIRE(l && x, "pmg_scatter_fwd_end: NULL argument");
-  if (!l->exchange)
+  if (!l->comm && !l->exchange)
     return PMG_OK; // single rank
-  if (l->exchange(l->user, 1, stream) != 0)
+  if (l->comm)
+    PMG_TRY(comm_exchange_end(l, S(stream)));
+  else if (l->exchange(l->user, 1, stream) != 0)
     return fail(PMG_ERR_INVALID, "exchange callback (end) failed");
   if (l->n_recv > 0)
     unpack_kernel<<<ew_blocks(l->n_recv), EW_THREADS, 0, S(stream)>>>(
@@ -614,12 +707,18 @@ extern "C" int pmg_scatter_fwd_end(pmg_layout l, double* x, pmg_stream stream)
 extern "C" int pmg_scatter_rev_begin(pmg_layout l, const double* x, pmg_stream stream)
 {
   PMG_REQUIRE(l && x, "pmg_scatter_rev_begin: NULL argument");
-  if (!l->exchange)
+  if (!l->comm && !l->exchange)
+  {
+    PMG_REQUIRE(l->n_send == 0 && l->n_recv == 0,
+                "scatter: the layout has neighbours but neither a communicator nor an exchange callback");
     return PMG_OK; // single rank
+  }
   if (l->n_recv > 0)
     pack_kernel<<<ew_blocks(l->n_recv), EW_THREADS, 0, S(stream)>>>(
         l->n_recv, l->recv_idx, x + l->size_local, l->recv_buf);
   PMG_HIP(hipGetLastError());
+  if (l->comm)
+    return comm_exchange_begin(l, true, S(stream));
   if (l->exchange(l->user, 2, stream) != 0)
     return fail(PMG_ERR_INVALID, "exchange callback (rev begin) failed");
   return PMG_OK;
@@ -629,9 +728,11 @@ extern "C" int pmg_scatter_rev_begin(pmg_layout l, const double* x, pmg_stream s
 extern "C" int pmg_scatter_rev_end(pmg_layout l, double* x, pmg_stream stream)
 {
   PMG_REQUIRE(l && x, "pmg_scatter_rev_end: NULL argument");
-  if (!l->exchange)
+  if (!l->comm && !l->exchange)
     return PMG_OK; // single rank
-  if (l->exchange(l->user, 3, stream) != 0)
+  if (l->comm)
+    PMG_TRY(comm_exchange_end(l, S(stream)));
+  else if (l->exchange(l->user, 3, stream) != 0)
     return fail(PMG_ERR_INVALID, "exchange callback (rev end) failed");
   if (l->n_send > 0)
     unpack_add_kernel<<<ew_blocks(l->n_send), EW_THREADS, 0, S(stream)>>>(l->n_send, l->send_idx,
@@ -707,20 +808,17 @@ extern "C" int pmg_vec_norm(pmg_layout l, const double* a, int norm_type, double
     return PMG_OK;
   }
   PMG_REQUIRE(norm_type == 1, "Norm type not supported"); // src/vector.hpp:388
-  PMG_REQUIRE(!l->allreduce || l->allreduce_max,
+  PMG_REQUIRE(l->comm || !l->allreduce || l->allreduce_max,
               "pmg_vec_norm: linf over several ranks needs pmg_layout_set_allreduce_max");
   int nb = ew_blocks(l->size_local);
   if (nb > RED_BLOCKS)
     nb = RED_BLOCKS;
   absmax_partial_kernel<<<nb, RED_THREADS, 0, S(stream)>>>(l->size_local, a, l->d_partials);
-  fold_kernel<true><<<1, RED_THREADS, 0, S(stream)>>>(nb, l->d_partials, l->d_partials + RED_BLOCKS);
+  fold_kernel<true><<<1, RED_THREADS, 0, S(stream)>>>(nb, l->d_partials, red_slot(l, 0));
   PMG_HIP(hipGetLastError());
-  PMG_HIP(hipMemcpyAsync(l->h_result, l->d_partials + RED_BLOCKS, sizeof(double),
-                         hipMemcpyDeviceToHost, S(stream)));
-  PMG_HIP(hipStreamSynchronize(S(stream)));
-  double v = l->h_result[0];
-  if (l->allreduce_max)
-    PMG_REQUIRE(l->allreduce_max(l->user, &v, 1) == 0, "pmg_vec_norm: the allreduce_max callback failed");
+  PMG_TRY(reduce_slots_async(l, 0, 1, true, S(stream)));
+  double v;
+  PMG_TRY(fetch_slots(l, 0, 1, &v, S(stream)));
   *result = v;
   return PMG_OK;
 }

@@ -34,6 +34,13 @@ def _dev_i8(a, device):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int8)).to(device)
 
 
+def set_merge_threshold(patch_dofs: int):
+    """Launch plan of operators created from now on: interior colours are merged into one atomic
+    launch when the interior list has at most ``patch_dofs`` patch dofs (0: always coloured
+    launches; negative: the library's measured defaults).  Process-wide; tests and tuning."""
+    call("pmg_set_merge_threshold", int(patch_dofs))
+
+
 class MatFreeLaplacian:
     """y = A x for the GLL-collocated stiffness operator, matrix-free.
 
@@ -123,6 +130,16 @@ class MatFreeLaplacian:
         call("pmg_laplacian_time_kernel", self._handle, ptr(x.data), ptr(y.data), int(reps), C.byref(out),
              current_stream())
         return out.value
+
+    def set_profiling(self, flag: bool):
+        """Bracket the stiffness launches of every application with HIP events (in-situ timing)."""
+        call("pmg_laplacian_set_profiling", self._handle, 1 if flag else 0)
+
+    def read_profile(self):
+        """(summed milliseconds, number of stiffness launches) recorded since the last read."""
+        ms, n = C.c_double(), C.c_longlong()
+        call("pmg_laplacian_read_profile", self._handle, C.byref(ms), C.byref(n))
+        return ms.value, n.value
 
     def __del__(self):
         try:

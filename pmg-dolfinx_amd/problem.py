@@ -16,14 +16,14 @@ from .pmg import MultigridPreconditioner
 from .vector import Layout, Vector
 
 
-def make_layout(lv, group=None, device="cuda") -> Layout:
+def make_layout(lv, group=None, device="cuda", comm=None) -> Layout:
     return Layout(lv.size_local, lv.num_ghosts, lv.neighbors, lv.send_counts, lv.recv_counts, lv.send_indices,
-                  lv.recv_indices, group=group, device=device)
+                  lv.recv_indices, group=group, device=device, comm=comm)
 
 
 class PoissonHierarchy:
     def __init__(self, n, orders=(1, 2, 4), kappa=2.0, cheb_its=3, proc_dims=None, rank=0, size=1, group=None,
-                 warp=None, eig_cg_its=20, eig_cg_rtol=1e-6, freq=(2, 3, 4), device="cuda"):
+                 warp=None, eig_cg_its=20, eig_cg_rtol=1e-6, freq=(2, 3, 4), device="cuda", comm=None):
         import torch
 
         self.orders = tuple(int(p) for p in orders)
@@ -41,7 +41,7 @@ class PoissonHierarchy:
         self.kappa = torch.full((part.ncells,), float(kappa), dtype=torch.float64, device=dev)  # :190-193
         for P in self.orders:
             lv = part.level(P)
-            layout = make_layout(lv, group, device)
+            layout = make_layout(lv, group, device, comm)
             op = MatFreeLaplacian(P, self.kappa, lv.dofmap, self.xgeom, self.geom_dofmap, lv.lcells, lv.bcells,
                                   lv.bc_marker, layout)  # :270-272
             op.compute_diag_inverse()  # replaces :274-279

@@ -28,17 +28,149 @@ def _dist():
     return dist
 
 
+class TorchComm:
+    """Exchange and reductions through ``torch.distributed`` (callbacks of the C ABI): the ``nccl``
+    backend is RCCL (asynchronous ``all_to_all_single`` on RCCL's stream); any other backend
+    (``gloo``) is staged through host memory.  The route for callers that bring their own
+    transport; the production route on one node is :class:`RcclComm`."""
+
+    native = None
+
+    def __init__(self, group=None, always_exchange=False):
+        dist = _dist()
+        self.group = group
+        self.initialized = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.initialized else 1
+        self.rank = dist.get_rank(group) if self.initialized else 0
+        # every rank of a multi-rank group takes part in every exchange (a collective), even one that
+        # happens to share no dof with anybody (always_exchange: also on a single-rank group, e.g. a
+        # rank that is its own periodic neighbour -- used to exercise this branch on one GPU)
+        self.distributed = self.world > 1 or (always_exchange and self.initialized)
+        self.staged = self.distributed and dist.get_backend(group) != "nccl"
+
+    def splits(self, layout):
+        send, recv = [0] * self.world, [0] * self.world
+        for r, s, c in zip(layout.neighbors, layout.send_counts, layout.recv_counts):
+            send[r] = s
+            recv[r] = c
+        return send, recv
+
+    def exchange(self, layout, phase):
+        dist = _dist()
+        if self.staged:
+            return self._exchange_staged(layout, phase)
+        L = layout
+        if phase == 0:  # forward begin: owners' packed values -> ghosts
+            L._work = dist.all_to_all_single(L.recv_buffer[: L.n_recv], L.send_buffer[: L.n_send], L._recv_splits,
+                                             L._send_splits, group=self.group, async_op=True)
+        elif phase == 2:  # reverse begin: ghost values -> owners
+            L._work = dist.all_to_all_single(L.send_buffer[: L.n_send], L.recv_buffer[: L.n_recv], L._send_splits,
+                                             L._recv_splits, group=self.group, async_op=True)
+        elif L._work is not None:  # 1, 3: make the compute stream wait for the arrival
+            L._work.wait()
+            L._work = None
+
+    def _exchange_staged(self, L, phase):
+        """Blocking exchange through host memory for process groups that cannot move device
+        buffers (gloo): runs the distributed path on machines without one GPU per rank."""
+        import torch
+
+        dist = _dist()
+        if phase in (0, 2):
+            fwd = phase == 0
+            src = L.send_buffer[: L.n_send] if fwd else L.recv_buffer[: L.n_recv]
+            dst = L.recv_buffer[: L.n_recv] if fwd else L.send_buffer[: L.n_send]
+            insp, outsp = (L._send_splits, L._recv_splits) if fwd else (L._recv_splits, L._send_splits)
+            host_in = src.cpu()  # synchronises with the pack kernel on the current stream
+            host_out = torch.empty(dst.numel(), dtype=torch.float64)
+            dist.all_to_all_single(host_out, host_in, outsp, insp, group=self.group)
+            dst.copy_(host_out)
+
+    def allreduce(self, layout, host, op):
+        import torch
+
+        dist = _dist()
+        t = torch.from_numpy(host.copy())
+        if dist.get_backend(self.group) == "nccl":
+            t = t.to(layout.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=self.group)
+        host[:] = t.cpu().numpy()
+
+    def all_to_all_host(self, layout, send, recv_count):
+        import torch
+
+        dist = _dist()
+        s = torch.from_numpy(np.ascontiguousarray(send))
+        r = torch.empty(recv_count, dtype=s.dtype)
+        if dist.get_backend(self.group) == "nccl":
+            s, r = s.to(layout.device), r.to(layout.device)
+        ss, rs = self.splits(layout)
+        dist.all_to_all_single(r, s, rs, ss, group=self.group)
+        return r.cpu().numpy()
+
+
+class RcclComm:
+    """The library's native communicator (``pmg_comm``): the neighbour exchange is one group of
+    ncclSend/ncclRecv per scatter, the reductions are ncclAllReduce on device scalars, both issued
+    by the library with no callback into Python.  One process per GPU; ``unique_id`` from rank 0
+    reaches the others through the caller's bootstrap (here: ``torch.distributed``)."""
+
+    def __init__(self, rank: int, size: int, unique_id: bytes):
+        if len(unique_id) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        self.rank, self.world = int(rank), int(size)
+        self.distributed = True
+        h = vp()
+        call("pmg_comm_create", C.byref(h), self.rank, self.world, C.c_char_p(unique_id))
+        self.native = h
+        self._host = None
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        call("pmg_comm_unique_id", buf)
+        return buf.raw
+
+    @classmethod
+    def from_torch(cls, group=None, device=None):
+        """Bootstrap over an initialised ``torch.distributed`` group (any backend)."""
+        import torch
+
+        dist = _dist()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        payload = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(payload, src=0, group=group, device=device)
+        c = cls(rank, world, payload[0])
+        c._host = TorchComm(group)  # set-up-time host exchanges (numpy arrays) only
+        return c
+
+    def all_to_all_host(self, layout, send, recv_count):
+        if self._host is None:
+            raise RuntimeError("RcclComm without a host-side bootstrap group cannot move host arrays")
+        return self._host.all_to_all_host(layout, send, recv_count)
+
+    def __del__(self):
+        try:
+            if getattr(self, "native", None) is not None:
+                _lib.lib().pmg_comm_destroy(self.native)
+                self.native = None
+        except Exception:
+            pass
+
+
 class Layout:
     """Sizes + halo plan of one function space on this rank.
 
     Parameters mirror the flattened IndexMap/Scatterer of the C ABI:
     ``neighbors`` (ranks, ascending), per-neighbour ``send_counts`` /
     ``recv_counts``, ``send_indices`` (owned positions, grouped by neighbour),
-    ``recv_indices`` (ghost positions relative to ``size_local``).
+    ``recv_indices`` (ghost positions relative to ``size_local``).  ``comm`` moves the data:
+    an :class:`RcclComm` (native), a :class:`TorchComm` or any object with the same
+    ``exchange`` / ``allreduce`` methods (callbacks); default: ``TorchComm(group)``.
     """
 
     def __init__(self, size_local, num_ghosts=0, neighbors=(), send_counts=(), recv_counts=(), send_indices=None,
-                 recv_indices=None, group=None, device="cuda", always_exchange=False):
+                 recv_indices=None, group=None, device="cuda", always_exchange=False, comm=None):
         import torch
 
         self.size_local = int(size_local)
@@ -59,7 +191,8 @@ class Layout:
         if n_recv and (ri.min() < 0 or ri.max() >= self.num_ghosts):
             raise ValueError("recv_indices out of the ghost range")
         self.send_indices_host, self.recv_indices_host = si, ri
-        self.distributed = bool(self.neighbors)
+        self.comm = comm if comm is not None else TorchComm(group, always_exchange)
+        self.distributed = bool(self.comm.distributed)
         self._work = None
         self._handle = None
         if self.device.type != "cuda":
@@ -68,95 +201,48 @@ class Layout:
         self.recv_indices = torch.from_numpy(ri).to(self.device)
         self.send_buffer = torch.zeros(max(n_send, 1), dtype=torch.float64, device=self.device)
         self.recv_buffer = torch.zeros(max(n_recv, 1), dtype=torch.float64, device=self.device)
-        dist = _dist()
-        self._world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        # every rank of a multi-rank group takes part in every exchange (a collective),
-        # even one that happens to share no dof with anybody
-        # (always_exchange: also on a single-rank group, e.g. a rank that is its own
-        # periodic neighbour -- used to exercise the RCCL branch on one GPU)
-        self.distributed = self._world > 1 or (always_exchange and dist.is_initialized())
-        self._staged = self.distributed and dist.get_backend(group) != "nccl"
-        self._splits()
+        native = getattr(self.comm, "native", None)
+        self._staged = bool(getattr(self.comm, "staged", False))
+        callbacks = self.distributed and native is None
+        if callbacks and hasattr(self.comm, "splits"):
+            self._send_splits, self._recv_splits = self.comm.splits(self)
         # callbacks must outlive the handle
-        self._cb_exchange = _lib.EXCHANGE_FN(self._exchange) if self.distributed else _lib.EXCHANGE_FN()
-        self._cb_allreduce = _lib.ALLREDUCE_FN(self._allreduce) if self.distributed else _lib.ALLREDUCE_FN()
+        self._cb_exchange = _lib.EXCHANGE_FN(self._exchange) if callbacks else _lib.EXCHANGE_FN()
+        self._cb_allreduce = _lib.ALLREDUCE_FN(self._allreduce) if callbacks else _lib.ALLREDUCE_FN()
         h = vp()
         call("pmg_layout_create", C.byref(h), self.size_local, self.num_ghosts, n_send, ptr(self.send_indices),
              ptr(self.send_buffer), n_recv, ptr(self.recv_indices), ptr(self.recv_buffer), self._cb_exchange,
              self._cb_allreduce, vp(0))
         self._handle = h
-        if self.distributed:
+        if callbacks:
             self._cb_allreduce_max = _lib.ALLREDUCE_FN(lambda user, values, n: self._allreduce(user, values, n, "max"))
             call("pmg_layout_set_allreduce_max", h, self._cb_allreduce_max)
+        if native is not None:
+            nb = np.ascontiguousarray(self.neighbors, dtype=np.int32)
+            sc = np.ascontiguousarray(self.send_counts, dtype=np.int32)
+            rc = np.ascontiguousarray(self.recv_counts, dtype=np.int32)
+            call("pmg_layout_set_comm", h, native, nb.size, nb.ctypes.data_as(_lib.c_ip),
+                 sc.ctypes.data_as(_lib.c_ip), rc.ctypes.data_as(_lib.c_ip))
+        if hasattr(self.comm, "register"):
+            self.comm.register(self)
 
-    # ---- per-rank split sizes for all_to_all_single ----
-    def _splits(self):
-        dist = _dist()
-        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
-        self._world = world
-        self._send_splits = [0] * world
-        self._recv_splits = [0] * world
-        for r, s, c in zip(self.neighbors, self.send_counts, self.recv_counts):
-            self._send_splits[r] = s
-            self._recv_splits[r] = c
-
-    # ---- callbacks (invoked from inside pmg_scatter_*; torch's current stream is
-    #      the stream the library was given) ----
+    # ---- callbacks (invoked from inside pmg_scatter_* / the reductions; torch's current stream
+    #      is the stream the library was given) ----
     def _exchange(self, user, phase, stream):
         try:
-            dist = _dist()
-            if self._staged:
-                return self._exchange_staged(phase)
-            if phase == 0:  # forward begin: owners' packed values -> ghosts
-                self._work = dist.all_to_all_single(
-                    self.recv_buffer[: self.n_recv], self.send_buffer[: self.n_send], self._recv_splits,
-                    self._send_splits, group=self.group, async_op=True)
-            elif phase == 2:  # reverse begin: ghost values -> owners
-                self._work = dist.all_to_all_single(
-                    self.send_buffer[: self.n_send], self.recv_buffer[: self.n_recv], self._send_splits,
-                    self._recv_splits, group=self.group, async_op=True)
-            else:  # 1, 3: make the compute stream wait for the arrival
-                if self._work is not None:
-                    self._work.wait()
-                    self._work = None
+            self.comm.exchange(self, phase)
             return 0
-        except Exception as e:  # never let an exception cross the C boundary
+        except Exception:  # never let an exception cross the C boundary
             import sys
             import traceback
 
             traceback.print_exc(file=sys.stderr)
             return 1
 
-    def _exchange_staged(self, phase):
-        """Exchange through host memory for process groups that cannot move device
-        buffers (gloo): blocking, no overlap.  Used to run the distributed path on
-        machines without RCCL-capable peers (e.g. two ranks sharing one GPU in the
-        test-suite); the RCCL path above is the production one."""
-        import torch
-
-        dist = _dist()
-        if phase in (0, 2):
-            fwd = phase == 0
-            src = self.send_buffer[: self.n_send] if fwd else self.recv_buffer[: self.n_recv]
-            dst = self.recv_buffer[: self.n_recv] if fwd else self.send_buffer[: self.n_send]
-            insp, outsp = (self._send_splits, self._recv_splits) if fwd else (self._recv_splits, self._send_splits)
-            host_in = src.cpu()  # synchronises with the pack kernel on the current stream
-            host_out = torch.empty(dst.numel(), dtype=torch.float64)
-            dist.all_to_all_single(host_out, host_in, outsp, insp, group=self.group)
-            dst.copy_(host_out)
-        return 0
-
     def _allreduce(self, user, values, n, op="sum"):
         try:
-            import torch
-
-            dist = _dist()
             host = np.ctypeslib.as_array(values, shape=(n,))
-            t = torch.from_numpy(host.copy())
-            if dist.get_backend(self.group) == "nccl":
-                t = t.to(self.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=self.group)
-            host[:] = t.cpu().numpy()
+            self.comm.allreduce(self, host, op)
             return 0
         except Exception:
             import sys
@@ -168,19 +254,11 @@ class Layout:
     # ---- host-side forward scatter of a numpy array (set-up and CPU tests) ----
     def scatter_fwd_host(self, x: np.ndarray) -> np.ndarray:
         """Owner -> ghost update of a host array of size_local + num_ghosts entries
-        with the same plan, over whatever backend the process group uses."""
-        import torch
-
-        dist = _dist()
-        if not (dist.is_available() and dist.is_initialized()) or not self.distributed:
+        with the same plan, over whatever transport the communicator has for host arrays."""
+        if not self.distributed:
             return x
-        self._splits()
-        send = torch.from_numpy(np.ascontiguousarray(x[self.send_indices_host]))
-        recv = torch.empty(self.n_recv, dtype=send.dtype)
-        if dist.get_backend(self.group) == "nccl":
-            send, recv = send.to(self.device), recv.to(self.device)
-        dist.all_to_all_single(recv, send, self._recv_splits, self._send_splits, group=self.group)
-        x[self.size_local + self.recv_indices_host] = recv.cpu().numpy()
+        recv = self.comm.all_to_all_host(self, x[self.send_indices_host], self.n_recv)
+        x[self.size_local + self.recv_indices_host] = recv
         return x
 
     @property

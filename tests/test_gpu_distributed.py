@@ -25,84 +25,121 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, dims, orders, q):
-    import torch
-    import torch.distributed as dist
+def _run_ranks(target, world, args, timeout=300):
+    """Spawn `world` processes running target(rank, world, port, *args, q); every worker puts
+    (rank, result) or (rank, exception text) on the queue.  Whatever happens -- a worker that dies
+    before reporting, a failure reported by one rank while the others sit in a collective -- every
+    process is terminated and joined before the test returns, so no rank is left holding the GPU."""
+    import queue as _queue
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        import pmg_dolfinx_amd as pm
-        from oracle import pmg_oracle as po
-
-        torch.cuda.set_device(0)
-        k = 3
-        H = pm.PoissonHierarchy(n, orders, kappa=2.0, cheb_its=k, proc_dims=dims, rank=rank, size=world, warp=warp)
-        out = {"eig": H.eig_ranges, "ghosts": [lv.num_ghosts for lv in H.levels]}
-        # operator apply on every level against the global oracle
-        gm = po.BoxMesh(n, warp=warp)
-        errs = []
-        for P, lv, layout, op in zip(orders, H.levels, H.layouts, H.operators):
-            A = po.Laplacian(P, 2.0, gm.dofmap(P), gm.xgeom, gm.geom_dofmap, gm.boundary_marker(P))
-            ug = np.random.default_rng(11).standard_normal(A.ndofs)
-            x, y = pm.Vector(layout), pm.Vector(layout)
-            xl = np.zeros(lv.ndofs)
-            xl[: lv.size_local] = ug[lv.local_to_global[: lv.size_local]]  # ghosts stale: apply must update them
-            x.data.copy_(torch.from_numpy(xl))
-            op(x, y)
-            ref = A.apply(ug)[lv.local_to_global[: lv.size_local]]
-            errs.append(float(np.abs(y.data_copy()[: lv.size_local] - ref).max() / np.abs(ref).max()))
-            # the ghosts of the input were refreshed as a side effect (src/laplacian.hpp:378,425)
-            assert np.array_equal(x.data_copy(), ug[lv.local_to_global])
-            # distributed reductions
-            assert abs(pm.inner_product(x, x) - ug @ ug) < 1e-10 * (ug @ ug)
-            assert pm.norm(x, "linf") == np.abs(ug).max()  # max-reduction over the ranks (src/vector.hpp:383-385)
-        out["apply_err"] = errs
-        # V-cycles against the single-domain oracle with the same smoother bounds
-        mesh, ops, sm, it, mg, b, eigs = po.build_hierarchy(n, orders, cheb_its=k, warp=warp)
-        for s, e in zip(sm, H.eig_ranges):
-            s.eig_range = e
-        lvf = H.levels[-1]
-        xv = H.new_vector()
-        xv.set(0.0)
-        xo = np.zeros_like(b)
-        verr = []
-        for _ in range(2):
-            rn = H.mg.apply(H.rhs[-1], xv, verbose=True)
-            xo = mg.apply(b, xo, compute_rnorm=True)
-            ref = xo[lvf.local_to_global[: lvf.size_local]]
-            verr.append((float(np.abs(xv.data_copy()[: lvf.size_local] - ref).max() / np.abs(xo).max()),
-                         abs(rn - mg.rnorm) / mg.rnorm))
-        out["vcycle_err"] = verr
-        out["eig_ref"] = eigs
-        q.put((rank, out))
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("dims,n", [((1, 1, 2), (3, 4, 8)), ((2, 1, 1), (6, 3, 4)), ((1, 2, 2), (3, 4, 6))])
-def test_ranks_share_one_gpu(dims, n, built):
-    """Two ranks (one neighbour each) and four ranks (three neighbours each, edge and corner
-    exchanges) on the one GPU."""
-    import torch
     import torch.multiprocessing as mp
 
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
-    orders = (1, 2, 4) if dims[0] * dims[1] * dims[2] == 2 else (1, 2)
-    world = dims[0] * dims[1] * dims[2]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, orders, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    for rank, out in res:
+    res = {}
+    try:
+        while len(res) < world:
+            try:
+                rank, out = q.get(timeout=5)
+            except _queue.Empty:
+                timeout -= 5
+                dead = [i for i, p in enumerate(procs) if p.exitcode not in (None, 0) and i not in res]
+                if dead:
+                    raise AssertionError(f"rank(s) {dead} died without reporting (exit codes "
+                                         f"{[procs[i].exitcode for i in dead]})")
+                if timeout <= 0:
+                    raise AssertionError("timed out waiting for the ranks")
+                continue
+            if isinstance(out, str):
+                raise AssertionError(f"rank {rank} failed:\n{out}")
+            res[rank] = out
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=30)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return [res[r] for r in range(world)]
+
+
+def _reporting(fn):
+    """Worker wrapper: report the traceback instead of dying silently."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(rank, world, port, *args):
+        q = args[-1]
+        try:
+            q.put((rank, fn(rank, world, port, *args[:-1])))
+        except BaseException:  # noqa: BLE001 -- reported to the parent, which fails the test
+            import traceback
+
+            q.put((rank, traceback.format_exc()))
+            raise
+
+    return wrapped
+
+
+def _rank_checks(pm, rank, world, n, dims, orders, comm=None):
+    """What every rank checks against the single-domain oracle: operator apply on every level (with
+    stale ghosts on input), distributed reductions, eigenvalue estimates, two V-cycles."""
+    import torch
+
+    from oracle import pmg_oracle as po
+
+    k = 3
+    H = pm.PoissonHierarchy(n, orders, kappa=2.0, cheb_its=k, proc_dims=dims, rank=rank, size=world, warp=warp,
+                            comm=comm)
+    out = {"eig": H.eig_ranges, "ghosts": [lv.num_ghosts for lv in H.levels],
+           "neighbors": [len(lv.neighbors) for lv in H.levels]}
+    # operator apply on every level against the global oracle
+    gm = po.BoxMesh(n, warp=warp)
+    errs = []
+    for P, lv, layout, op in zip(orders, H.levels, H.layouts, H.operators):
+        A = po.Laplacian(P, 2.0, gm.dofmap(P), gm.xgeom, gm.geom_dofmap, gm.boundary_marker(P))
+        ug = np.random.default_rng(11).standard_normal(A.ndofs)
+        x, y = pm.Vector(layout), pm.Vector(layout)
+        xl = np.zeros(lv.ndofs)
+        xl[: lv.size_local] = ug[lv.local_to_global[: lv.size_local]]  # ghosts stale: apply must update them
+        x.data.copy_(torch.from_numpy(xl))
+        op(x, y)
+        ref = A.apply(ug)[lv.local_to_global[: lv.size_local]]
+        errs.append(float(np.abs(y.data_copy()[: lv.size_local] - ref).max() / np.abs(ref).max()))
+        # the ghosts of the input were refreshed as a side effect (src/laplacian.hpp:378,425)
+        assert np.array_equal(x.data_copy(), ug[lv.local_to_global])
+        # distributed reductions
+        assert abs(pm.inner_product(x, x) - ug @ ug) < 1e-10 * (ug @ ug)
+        assert pm.norm(x, "linf") == np.abs(ug).max()  # max-reduction over the ranks (src/vector.hpp:383-385)
+    out["apply_err"] = errs
+    # V-cycles against the single-domain oracle with the same smoother bounds
+    mesh, ops, sm, it, mg, b, eigs = po.build_hierarchy(n, orders, cheb_its=k, warp=warp)
+    for s, e in zip(sm, H.eig_ranges):
+        s.eig_range = e
+    lvf = H.levels[-1]
+    xv = H.new_vector()
+    xv.set(0.0)
+    xo = np.zeros_like(b)
+    verr = []
+    for _ in range(2):
+        rn = H.mg.apply(H.rhs[-1], xv, verbose=True)
+        xo = mg.apply(b, xo, compute_rnorm=True)
+        ref = xo[lvf.local_to_global[: lvf.size_local]]
+        verr.append((float(np.abs(xv.data_copy()[: lvf.size_local] - ref).max() / np.abs(xo).max()),
+                     abs(rn - mg.rnorm) / mg.rnorm))
+    out["vcycle_err"] = verr
+    out["eig_ref"] = eigs
+    return out
+
+
+def _assert_rank_results(res):
+    for out in res:
         assert all(g > 0 for g in out["ghosts"])
         assert max(out["apply_err"]) < 1e-12, out["apply_err"]
         for got, ref in zip(out["eig"], out["eig_ref"]):
@@ -111,7 +148,150 @@ def test_ranks_share_one_gpu(dims, n, built):
             assert e < 1e-10 and rn < 1e-8
 
 
-def _rccl_worker(port, q):
+def _worker_body(rank, world, port, n, dims, orders):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pmg_dolfinx_amd as pm
+
+        torch.cuda.set_device(0)
+        return _rank_checks(pm, rank, world, n, dims, orders)
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker(rank, world, port, n, dims, orders, q):
+    _reporting(_worker_body)(rank, world, port, n, dims, orders, q)
+
+
+@pytest.mark.parametrize("dims,n", [((1, 1, 2), (3, 4, 8)), ((2, 1, 1), (6, 3, 4)), ((1, 2, 2), (3, 4, 6))])
+def test_ranks_share_one_gpu(dims, n, built):
+    """Two ranks (one neighbour each) and four ranks (three neighbours each, edge and corner
+    exchanges) on the one GPU."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    orders = (1, 2, 4) if dims[0] * dims[1] * dims[2] == 2 else (1, 2)
+    world = dims[0] * dims[1] * dims[2]
+    _assert_rank_results(_run_ranks(_worker, world, (n, dims, orders)))
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 3's partition -- 2 x 2 x 2 bricks, every rank with 7 neighbours (3 faces, 3 edges,
+# 1 corner) -- on the one GPU of the test box: the eight ranks are eight host THREADS of one process
+# (the box admits at most 6 processes on its GPU), each with its own HIP stream and its own library
+# objects; the exchange callback of the C ABI moves the packed buffers between the ranks' staging
+# buffers with stream-ordered device copies.
+class _ThreadWorld:
+    def __init__(self, n):
+        import threading
+
+        self.n = n
+        self.barrier = threading.Barrier(n)
+        self.layouts = [dict() for _ in range(n)]
+        self.slots = [None] * n
+
+    def wait(self):
+        self.barrier.wait(timeout=240)
+
+
+class _ThreadComm:
+    native = None
+    staged = False
+    distributed = True
+
+    def __init__(self, world, rank):
+        self.W, self.rank, self.world = world, rank, world.n
+        self._count = 0
+
+    def register(self, layout):  # layouts are created in the same order on every rank
+        layout._tid = self._count
+        self.W.layouts[self.rank][self._count] = layout
+        self._count += 1
+
+    def exchange(self, L, phase):
+        import torch
+
+        st = torch.cuda.current_stream()
+        W = self.W
+        if phase in (0, 2):
+            fwd = phase == 0
+            L._ev_packed = torch.cuda.Event()
+            L._ev_packed.record(st)
+            W.wait()  # every rank has packed (on its own stream) and published its event
+            off = 0
+            for i, nb in enumerate(L.neighbors):
+                peer = W.layouts[nb][L._tid]
+                cnt = (L.recv_counts if fwd else L.send_counts)[i]
+                j = peer.neighbors.index(self.rank)
+                pc = peer.send_counts if fwd else peer.recv_counts
+                assert pc[j] == cnt, "the two sides of a halo plan disagree"
+                po_ = sum(pc[:j])
+                st.wait_event(peer._ev_packed)
+                src = (peer.send_buffer if fwd else peer.recv_buffer)[po_: po_ + cnt]
+                dst = (L.recv_buffer if fwd else L.send_buffer)[off: off + cnt]
+                dst.copy_(src)
+                off += cnt
+            L._ev_copied = torch.cuda.Event()
+            L._ev_copied.record(st)
+        else:
+            W.wait()  # every rank has enqueued its copies: nobody repacks a buffer that is still being read
+            for nb in L.neighbors:
+                st.wait_event(W.layouts[nb][L._tid]._ev_copied)
+
+    def allreduce(self, L, host, op):
+        W = self.W
+        W.slots[self.rank] = host.copy()
+        W.wait()
+        vals = np.stack(W.slots)
+        tot = vals.max(axis=0) if op == "max" else vals.sum(axis=0)
+        W.wait()
+        host[:] = tot
+
+
+def test_eight_ranks_2x2x2_as_threads(built):
+    import threading
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pmg_dolfinx_amd as pm
+
+    dims, n, orders = (2, 2, 2), (8, 8, 8), (1, 2, 4)  # 4 x 4 x 4 cells per brick
+    world = 8
+    W = _ThreadWorld(world)
+    res, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                res[rank] = _rank_checks(pm, rank, world, n, dims, orders, comm=_ThreadComm(W, rank))
+                torch.cuda.current_stream().synchronize()
+        except BaseException:  # noqa: BLE001
+            import traceback
+
+            errors.append((rank, traceback.format_exc()))
+            W.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=900)
+    assert not errors, "\n".join(f"rank {r}:\n{tb}" for r, tb in errors)
+    assert all(r is not None for r in res)
+    assert all(nb == 7 for out in res for nb in out["neighbors"])  # faces, edges and the corner
+    _assert_rank_results(res)
+
+
+def _rccl_worker_body(rank, world, port):
     """One rank, nccl (= RCCL) process group: the rank is its own neighbour, so the
     production exchange branch (async all_to_all_single on RCCL's stream, wait on the
     compute stream) and the device all-reduce run for real on the one GPU."""
@@ -157,24 +337,106 @@ def _rccl_worker(port, q):
         v = H.new_vector()
         v.set(0.0)
         out["rnorm"] = H.mg.apply(H.rhs[-1], v, verbose=True)
-        q.put(out)
+        return out
     finally:
         dist.destroy_process_group()
 
 
-def test_rccl_branch_single_rank(built):
+def _rccl_worker(rank, world, port, q):
+    _reporting(_rccl_worker_body)(rank, world, port, q)
+
+
+def _native_worker_body(rank, world, port):
+    """The library's own communicator (pmg_comm: RCCL bound at run time, grouped ncclSend/ncclRecv on
+    its own stream, ncclAllReduce on device scalars) with one rank that is its own neighbour -- RCCL
+    needs one GPU per rank, so on this box that is the whole of the native path that can run; the
+    plan logic it shares with the other transports is covered by the multi-rank tests above."""
     import torch
-    import torch.multiprocessing as mp
+
+    import pmg_dolfinx_amd as pm
+    from oracle import pmg_oracle as po
+
+    torch.cuda.set_device(0)
+    comm = pm.RcclComm(0, 1, pm.RcclComm.unique_id())
+    rng = np.random.default_rng(6)
+    n, m = 120_000, 40_000
+    send = rng.permutation(n)[:m].astype(np.int32)
+    # two "neighbours", both this rank, with different counts: segment offsets matter
+    m0 = 15_000
+    layout = pm.Layout(n, m, neighbors=[0, 0], send_counts=[m0, m - m0], recv_counts=[m0, m - m0], send_indices=send,
+                       recv_indices=np.arange(m, dtype=np.int32), comm=comm)
+    out = {}
+    side = torch.cuda.Stream()
+    for name, stream in (("default", torch.cuda.current_stream()), ("side", side)):
+        with torch.cuda.stream(stream):
+            x = pm.Vector(layout)
+            a = rng.standard_normal(n + m)
+            x.data.copy_(torch.from_numpy(a))
+            for _ in range(3):
+                x.scatter_fwd_begin()
+                pm.scale(x, 1.0)  # work between begin and end, like the interior cells
+                x.scatter_fwd_end()
+            got = x.data_copy()
+            out[name + "_fwd"] = bool(np.array_equal(got[n:], a[send]) and np.array_equal(got[:n], a[:n]))
+            x.scatter_rev_begin()
+            x.scatter_rev_end()
+            ref = a[:n].copy()
+            np.add.at(ref, send, a[send])
+            out[name + "_rev"] = float(np.abs(x.data_copy()[:n] - ref).max())
+            out[name + "_dot"] = abs(pm.inner_product(x, x) - ref @ ref) / (ref @ ref)
+            out[name + "_linf"] = bool(pm.norm(x, "linf") == np.abs(x.data_copy()[:n]).max())
+    # the solvers on a layout with a communicator: reductions go through ncclAllReduce, the CG keeps its
+    # scalars on the device; same iterates as the oracle
+    orders, k, nmesh = (1, 2, 4), 3, 4
+    H = pm.PoissonHierarchy(nmesh, orders, cheb_its=k, warp=warp, comm=comm)
+    mesh, ops, sm, it, mg, b, eigs = po.build_hierarchy(nmesh, orders, cheb_its=k, warp=warp)
+    out["eig_err"] = max(abs(g[1] - e[1]) / e[1] for g, e in zip(H.eig_ranges, eigs))
+    for s_, e in zip(sm, H.eig_ranges):
+        s_.eig_range = e
+    v = H.new_vector()
+    v.set(0.0)
+    rn = H.mg.apply(H.rhs[-1], v, verbose=True)
+    xo = mg.apply(b, np.zeros_like(b), compute_rnorm=True)
+    out["vcycle_err"] = float(np.abs(v.data_copy() - xo).max() / np.abs(xo).max())
+    out["rnorm_err"] = abs(rn - mg.rnorm) / mg.rnorm
+    cg = pm.CGSolver(H.layouts[-1])
+    cg.set_max_iterations(30)
+    cg.set_tolerance(1e-9)
+    xs = H.new_vector()
+    xs.set(0.0)
+    out["pcg_its"] = cg.solve(H.operators[-1], xs, H.rhs[-1], preconditioner=H.mg)
+    ocg = po.CGSolver()
+    ocg.set_max_iterations(30)
+    ocg.set_tolerance(1e-9)
+    xr = np.zeros_like(b)
+    out["pcg_its_ref"] = ocg.solve(ops[-1], xr, b, precond=lambda r: mg.apply(r, np.zeros_like(r)))
+    out["pcg_err"] = float(np.abs(xs.data_copy() - xr).max() / np.abs(xr).max())
+    return out
+
+
+def _native_worker(rank, world, port, q):
+    _reporting(_native_worker_body)(rank, world, port, q)
+
+
+def test_native_rccl_communicator_single_rank(built):
+    import torch
 
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
-    p.start()
-    out = q.get(timeout=300)
-    p.join(timeout=60)
-    assert p.exitcode == 0
+    (out,) = _run_ranks(_native_worker, 1, ())
+    for s in ("default", "side"):
+        assert out[s + "_fwd"]
+        assert out[s + "_rev"] < 1e-14 and out[s + "_dot"] < 1e-13 and out[s + "_linf"]
+    assert out["eig_err"] < 1e-8 and out["vcycle_err"] < 1e-10 and out["rnorm_err"] < 1e-8
+    assert out["pcg_its"] == out["pcg_its_ref"] and out["pcg_err"] < 1e-8
+
+
+def test_rccl_branch_single_rank(built):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    (out,) = _run_ranks(_rccl_worker, 1, ())
     for s in ("default", "side"):
         assert out[s + "_fwd"]
         assert out[s + "_rev"] < 1e-14 and out[s + "_dot"] < 1e-13 and out[s + "_linf"]

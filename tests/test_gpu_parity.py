@@ -260,6 +260,35 @@ def test_vcycle_parity(pm, orders, n):
         assert abs(rn - mg.rnorm) < 1e-9 * max(mg.rnorm, 1e-30) + 1e-12
 
 
+def test_config2_full_size_vcycle_against_c_oracle(pm):
+    """BASELINE config 2 at its full size -- 64^3 hexes, p = 4 -> 2 -> 1, Chebyshev(3), 17 M fine dofs:
+    the V-cycle the bench times (coloured launches on p4 and p2, patch transfers, streaming cache
+    policy) against the C/OpenMP oracle, three cycles from x = 0, plus the fine operator alone."""
+    from oracle import c_oracle as co
+
+    n, orders, k = 64, (1, 2, 4), 3
+    h = pm.PoissonHierarchy(n, orders, kappa=2.0, cheb_its=k)
+    assert h.operators[-1].launches_per_apply() >= 8  # the coloured path
+    part = h.part
+    cl = [co.CLevel(p, 2.0, part.level(p).dofmap, part.xgeom, part.geom_dofmap, part.level(p).bc_marker)
+          for p in orders]
+    ci = [co.CInterp(cl[i], cl[i + 1]) for i in range(len(orders) - 1)]
+    cm = co.CMultigrid(cl, ci, [e[1] for e in h.eig_ranges], k)
+    u = np.random.default_rng(3).standard_normal(h.levels[-1].ndofs)
+    xu, yu = _vec(pm, h.layouts[-1], u), h.new_vector()
+    h.operators[-1](xu, yu)
+    assert _relerr(yu.data_copy(), cl[-1].apply(u)) < 1e-12
+    del xu, yu
+    b = h.rhs[-1].data_copy()
+    x = h.new_vector()
+    x.set(0.0)
+    xo = np.zeros_like(b)
+    for cyc in range(3):
+        h.mg.apply(h.rhs[-1], x)
+        cm.apply(b, xo)
+        assert _relerr(x.data_copy(), xo) < 1e-10, cyc
+
+
 def test_errors(pm):
     part = pm.BoxPartition(2)
     lv = part.level(1)
@@ -568,22 +597,39 @@ def test_apply_parity_random_small_meshes(pm):
         assert _relerr(y.data_copy(), A.apply(u)) < 1e-12, (case, P, n)
 
 
-@pytest.mark.parametrize("P,n", [(1, (8, 8, 16)), (2, (8, 8, 16)), (4, (4, 4, 16)), (6, (4, 4, 4))])
-def test_merged_and_coloured_launches_agree(pm, P, n, monkeypatch):
+# every degree, on meshes that give at least two full patches per colour (patch shapes:
+# patches.hpp patch_shape) -- the coloured launches are the path the bench times
+@pytest.mark.parametrize("P,n", [(1, (8, 8, 32)), (2, (8, 8, 32)), (3, (4, 4, 32)), (4, (4, 4, 32)), (5, (4, 4, 16)),
+                                 (6, (4, 4, 8)), (7, (4, 4, 8)), (8, (2, 2, 16))])
+def test_merged_and_coloured_launches_agree(pm, P, n):
     """The same operator built with the interior colours as separate launches (plain stores) and
     merged into one launch (atomics): same result, and both equal the oracle."""
-    part, lv, layout, _, A = _single_level(pm, n, P, warped="twist")
+    from oracle import c_oracle as co
+
+    part = pm.BoxPartition(n, warp=twist)
+    lv = part.level(P)
+    layout = pm.make_layout(lv)
+    A = co.CLevel(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.bc_marker)
     u = np.random.default_rng(7).standard_normal(lv.ndofs)
     x = _vec(pm, layout, u)
     got = {}
-    for name, below in (("coloured", "0"), ("merged", "1000000000")):
-        monkeypatch.setenv("PMG_MERGE_BELOW", below)
-        op = pm.MatFreeLaplacian(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells, lv.bc_marker,
-                                 layout)
-        y = pm.Vector(layout)
-        y.set(1.0)
-        op(x, y)
-        got[name] = (y.data_copy(), op.launches_per_apply())
-    assert got["coloured"][1] > 1 and got["merged"][1] == 1
+    try:
+        for name, below in (("coloured", 0), ("merged", 10**12)):
+            pm.set_merge_threshold(below)
+            op = pm.MatFreeLaplacian(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells,
+                                     lv.bc_marker, layout)
+            y = pm.Vector(layout)
+            y.set(1.0)
+            op(x, y)
+            first = y.data_copy()
+            op(x, y)  # second application onto the first one's output: nothing may carry over
+            got[name] = (first, op.launches_per_apply(), y.data_copy())
+    finally:
+        pm.set_merge_threshold(-1)
+    assert got["coloured"][1] >= 8 and got["merged"][1] == 1
     ref = A.apply(u)
-    assert _relerr(got["coloured"][0], ref) < 1e-12 and _relerr(got["merged"][0], ref) < 1e-12
+    for name in ("coloured", "merged"):
+        assert _relerr(got[name][0], ref) < 1e-12, name
+        assert _relerr(got[name][2], ref) < 1e-12, name
+    # the coloured path uses no atomics: run-to-run identical
+    assert np.array_equal(got["coloured"][0], got["coloured"][2])

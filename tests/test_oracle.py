@@ -100,7 +100,6 @@ def test_matfree_equals_assembled_and_c(P, wf, built):
         assert np.abs(M @ u - y).max() < 1e-12 * np.abs(y).max()
         assert abs(M - M.T).max() < 1e-12 * abs(M).max()
         assert np.abs(A.diagonal() - M.diagonal()).max() < 1e-12 * M.diagonal().max()
-    assert abs(v @ A.apply(u) - u @ A.apply(v)) < 1e-10 * np.abs(y).max() * np.abs(v).sum() or True
     uu, vv = u * ~b, v * ~b
     assert abs(vv @ A.apply(uu) - uu @ A.apply(vv)) < 1e-11 * np.linalg.norm(A.apply(uu)) * np.linalg.norm(vv)
     assert np.abs(A.diagonal() - Cl.diagonal()).max() < 1e-12 * A.diagonal().max()
@@ -116,6 +115,93 @@ def test_linear_field_energy():
         assert abs(xc @ y - 2.0) < 1e-12
         interior = ~m.boundary_marker(P).astype(bool)
         assert np.abs(y[interior]).max() < 1e-12
+
+
+def test_polynomial_energy():
+    """u = x^P lies in the space and (u')^2 has degree 2P-2 <= 2P-1, which the (P+1)-point GLL rule
+    integrates exactly: u^T A u = kappa * int_0^1 (P x^(P-1))^2 dx = kappa P^2 / (2P - 1), for the numpy
+    and the C restatement (uniform box, several cells per direction)."""
+    for P in (1, 2, 3, 4, 6, 8):
+        m = po.BoxMesh((3, 2, 2) if P < 6 else (2, 1, 1))
+        nobc = np.zeros(m.ndofs(P), dtype=np.int8)
+        u = m.dof_coordinates(P)[:, 0] ** P
+        for A in (po.Laplacian(P, 2.0, m.dofmap(P), m.xgeom, m.geom_dofmap, nobc),
+                  co.CLevel(P, 2.0, m.dofmap(P), m.xgeom, m.geom_dofmap, nobc)):
+            assert abs(u @ A.apply(u) - 2.0 * P * P / (2 * P - 1)) < 1e-11 * P * P
+
+
+def _independent_element_matrix(P, xv, kappa):
+    """K_ij = kappa sum_q w_q |det J_q| (J_q^-T grad phi_i(q)) . (J_q^-T grad phi_j(q)) on ONE trilinear cell
+    with vertices xv [8, 3] (k = i*4 + j*2 + l), built without anything the oracle uses: GLL nodes from
+    numpy's Legendre class, 1-D Lagrange polynomials as explicit np.poly1d products, the full 3-D gradient
+    table [nq, N, 3] (no D x I x I factorisation, no sum factorisation), numpy.linalg for J^-1 and det.
+    The formula is src/laplacian.hpp:72-111 (G = J^-1 J^-T det J w) composed with :195-270 (B^T G B)."""
+    from numpy.polynomial import legendre as L
+
+    n = P + 1
+    # GLL nodes on [-1, 1]: +-1 and the roots of P'_{n-1}; weights 2 / (n (n-1) P_{n-1}(x)^2)
+    c = np.zeros(n)
+    c[-1] = 1.0
+    xi = np.concatenate([[-1.0], np.sort(L.legroots(L.legder(c))), [1.0]])
+    w = 2.0 / (n * (n - 1) * L.legval(xi, c) ** 2)
+    xi, w = 0.5 * (xi + 1.0), 0.5 * w  # -> [0, 1]
+    lag = []
+    for a in range(n):
+        others = np.delete(xi, a)
+        lag.append(np.poly1d(others, r=True) / np.prod(xi[a] - others))
+    val = np.array([[lag[a](x) for a in range(n)] for x in xi])           # val[q, a] = l_a(x_q)
+    der = np.array([[lag[a].deriv()(x) for a in range(n)] for x in xi])   # der[q, a] = l_a'(x_q)
+    N = n**3
+    Kmat = np.zeros((N, N))
+    for qa in range(n):
+        for qb in range(n):
+            for qc in range(n):
+                x, y, z = xi[qa], xi[qb], xi[qc]
+                # trilinear coordinate map: J[i][j] = d x_i / d X_j
+                J = np.zeros((3, 3))
+                for i in range(2):
+                    for j in range(2):
+                        for l in range(2):
+                            px, py, pz = (x if i else 1 - x), (y if j else 1 - y), (z if l else 1 - z)
+                            dx, dy, dz = (1.0 if i else -1.0), (1.0 if j else -1.0), (1.0 if l else -1.0)
+                            g = np.array([dx * py * pz, px * dy * pz, px * py * dz])
+                            J += np.outer(xv[i * 4 + j * 2 + l], g)
+                Jinv = np.linalg.inv(J)
+                grad = np.empty((N, 3))  # reference gradient of every basis function at this point
+                for a in range(n):
+                    for b in range(n):
+                        for cc in range(n):
+                            grad[(a * n + b) * n + cc] = (der[qa, a] * val[qb, b] * val[qc, cc],
+                                                          val[qa, a] * der[qb, b] * val[qc, cc],
+                                                          val[qa, a] * val[qb, b] * der[qc, cc])
+                pg = grad @ Jinv  # rows: J^-T grad
+                Kmat += kappa * w[qa] * w[qb] * w[qc] * abs(np.linalg.det(J)) * (pg @ pg.T)
+    return Kmat
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 4])
+def test_element_matrix_independent(P, built):
+    """The sum-factorised element contraction of the oracle (numpy and C) against an element matrix
+    assembled from first principles on a genuinely trilinear (twisted) cell."""
+    m = po.BoxMesh(1, warp=lambda x: twist(x) + 0.07 * x[:, [2, 0, 1]] ** 2)
+    nobc = np.zeros(m.ndofs(P), dtype=np.int8)
+    Kref = _independent_element_matrix(P, m.xgeom[m.geom_dofmap[0]], 1.7)
+    A = po.Laplacian(P, 1.7, m.dofmap(P), m.xgeom, m.geom_dofmap, nobc)
+    Ke = A.element_matrices()[0]
+    assert np.abs(Ke - Kref).max() < 1e-12 * np.abs(Kref).max()
+    Cl = co.CLevel(P, 1.7, m.dofmap(P), m.xgeom, m.geom_dofmap, nobc)
+    Kc = np.stack([Cl.apply(e) for e in np.eye(m.ndofs(P))], axis=1)  # one cell: dof = local index
+    assert np.array_equal(m.dofmap(P)[0], np.arange(m.ndofs(P)))
+    assert np.abs(Kc - Kref).max() < 1e-12 * np.abs(Kref).max()
+    # and the assembled operator of a two-cell mesh is the sum of two such matrices
+    m2 = po.BoxMesh((2, 1, 1), warp=twist)
+    A2 = po.Laplacian(P, 1.0, m2.dofmap(P), m2.xgeom, m2.geom_dofmap, np.zeros(m2.ndofs(P), dtype=np.int8))
+    M = np.zeros((m2.ndofs(P),) * 2)
+    for c in range(2):
+        dm = m2.dofmap(P)[c]
+        M[np.ix_(dm, dm)] += _independent_element_matrix(P, m2.xgeom[m2.geom_dofmap[c]], 1.0)
+    u = np.random.default_rng(P).standard_normal(m2.ndofs(P))
+    assert np.abs(A2.apply(u) - M @ u).max() < 1e-12 * np.abs(M @ u).max()
 
 
 def test_transfers():
