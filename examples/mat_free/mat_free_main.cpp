@@ -15,12 +15,15 @@
 #include <iostream>
 
 using namespace pmg_amd;
+using T = double;                                          // examples/mat_free/main.cpp:31
+using DeviceVector = acc::Vector<T, acc::Device::HIP>;
 
 int main(int argc, char** argv)
 {
   int n = 16, degree = 1, nreps = 1000;
   std::size_t ndofs = 0;
   bool mat_comp = false;
+  std::size_t batch_size = 0; // :38,46-50: cells whose geometry tensor is held at a time (0 = all, resident)
   for (int i = 1; i < argc; ++i)
   {
     auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
@@ -34,9 +37,12 @@ int main(int argc, char** argv)
       nreps = std::atoi(next());
     else if (!std::strcmp(argv[i], "--mat_comp"))
       mat_comp = true;
+    else if (!std::strcmp(argv[i], "--batch_size"))
+      batch_size = std::strtoull(next(), nullptr, 10);
     else
     {
-      std::cout << "usage: mat_free [--n cells_per_direction | --ndofs N] [--degree P] [--nreps R] [--mat_comp]\n";
+      std::cout << "usage: mat_free [--n cells_per_direction | --ndofs N] [--degree P] [--nreps R] [--mat_comp] "
+                   "[--batch_size cells]\n";
       return !std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h") ? 0 : 2;
     }
   }
@@ -63,14 +69,16 @@ int main(int argc, char** argv)
     auto [lcells, bcells] = compute_boundary_cells(V.dofmap, mesh.ncells(), mesh.ncells(), nd * nd * nd, V.ndofs);
 
     auto t0 = std::chrono::steady_clock::now();
-    acc::MatFreeLaplacian op(degree, kappa.span(), dofmap.span(), xgeom.span(), xdofmap.span(), {}, {}, lcells,
-                             bcells, bc.span());
-    acc::Vector u(map, 1), y(map, 1);
+    acc::MatFreeLaplacian<T> op(degree, kappa.span(), dofmap.span(), xgeom.span(), xdofmap.span(), {}, {}, lcells,
+                                bcells, bc.span(), batch_size);
+    DeviceVector u(map, 1), y(map, 1);
     u.set(1.0);
     op(u, y); // creates the handle (geometry, patches) and warms up
     hip_check(hipDeviceSynchronize(), "sync");
     auto t1 = std::chrono::steady_clock::now();
     std::cout << "Create matfree operator: " << std::chrono::duration<double>(t1 - t0).count() << " s\n";
+    std::printf("Geometry tensor held: %.3f MB%s\n", pmg_laplacian_geometry_bytes(op.handle(map)) * 1e-6,
+                batch_size ? " (recomputed batch by batch in every apply)" : " (resident)");
 
     hipEvent_t e0, e1;
     hip_check(hipEventCreate(&e0), "event");
@@ -113,7 +121,7 @@ int main(int argc, char** argv)
                                         * (6 * at(i, j, k) - at(i - 1, j, k) - at(i + 1, j, k) - at(i, j - 1, k)
                                            - at(i, j + 1, k) - at(i, j, k - 1) - at(i, j, k + 1));
           }
-      acc::Vector zd(map, 1), e(map, 1);
+      DeviceVector zd(map, 1), e(map, 1);
       zd.copy_from_host(z);
       acc::axpy(e, -1.0, y, zd);
       std::printf("Norm of z = %.15e\n", acc::norm(zd));

@@ -1,193 +1,450 @@
-// p-multigrid driver: the MI355X counterpart of the reference's
-// examples/pmg/main.cpp:solve (:41-380), written against the same concept names
-// (include/pmg_amd.hpp).  Defaults are BASELINE config 2: 64^3 hexes, degrees
-// 1,2,4, Chebyshev(3).  Per level: operator (:270-272), matrix-free inverse
-// diagonal (replaces the CSR assembly of :274-279), load vector of
-// f = -div(kappa grad(sin 2 pi x sin 3 pi y sin 4 pi z)) / kappa sampled at the
-// GLL nodes (examples/pmg/poisson.py:6-8,30,35-40; :289-300), eigenvalue estimate
-// by 20 iterations of Jacobi-CG on b = 1 (:306-327); then the interpolators
-// (:336-341), the V-cycle (:348-355) and `--cycles` applications from x = 0 with
-// the residual norm printed after each (:362-367, verbose).  `--pcg` additionally
-// solves with CG preconditioned by the cycle.  Single rank.
+// p-multigrid driver: the MI355X counterpart of the reference's examples/pmg/main.cpp:solve
+// (:41-380), written against the reference's own type spellings through include/pmg_amd.hpp
+// (PMG_AMD_DOLFINX_NAMESPACE): the smoother set-up, interpolators, V-cycle wiring and the cycle loop
+// below are the reference's lines :306-365; what stands above them replaces dolfinx (mesh, function
+// spaces, index maps, load vector).  Defaults are BASELINE config 2: 64^3 hexes, degrees 1,2,4,
+// Chebyshev(3).  Per level: operator (:270-272), matrix-free inverse diagonal (replaces the CSR
+// assembly of :274-279), load vector of f = -div(kappa grad(sin 2 pi x sin 3 pi y sin 4 pi z)) / kappa
+// sampled at the GLL nodes (examples/pmg/poisson.py:6-8,30,35-40; :289-300).
+//
+//   --amg            coarse solver on the degree-1 level (:331-335): CG <= 60 iterations, rtol 1e-5,
+//                    preconditioned by the library's algebraic multigrid (hypre's role)
+//   --amg-cycles N   the same hierarchy as N stationary AMG cycles instead of the Krylov solve
+//   --coarse-cg      Jacobi-preconditioned CG (60 iterations) as the coarse solver
+//   --pcg            additionally solve with CG preconditioned by the cycle (random right-hand side
+//                    with --random-rhs)
+//   --ranks px,py,pz one process per GPU and brick (the reference runs under mpirun -n 8,
+//                    examples/pmg/submit.sh:29): halo exchange and reductions on the library's RCCL
+//                    communicator.  Rank and world size come from --rank / RANK (OMPI_COMM_WORLD_RANK,
+//                    PMI_RANK); the GPU from LOCAL_RANK; rank 0 publishes the communicator id in
+//                    --id-file.  examples/pmg/run_ranks.sh launches the processes.
+//   --check-partition px,py,pz   host-only consistency check of the brick partition (no GPU)
+//   --output FILE    write the solution as a legacy VTK file of the fine-level GLL points (:369-379)
+#define PMG_AMD_DOLFINX_NAMESPACE
 #include "../common/box_mesh.hpp"
+#include "../common/brick_partition.hpp"
 #include "pmg_amd.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
+#include <random>
 #include <sstream>
+#include <thread>
 #include <tuple>
 
-using namespace pmg_amd;
-using DeviceVector = acc::Vector;
+using namespace dolfinx; // examples/pmg/main.cpp:29
+using T = double;        // :30
+using DeviceVector = dolfinx::acc::Vector<T, acc::Device::HIP>; // :33
+using pmg_amd::check;
+using pmg_amd::device_array;
+using pmg_amd::hip_check;
+
+/// The coarse solver of the reference is CoarseSolverType<T> (src/amg.hpp): anything with
+/// solve(DeviceVector& x, DeviceVector& y).  Here: the library's AMG (Krylov or stationary mode).
+template <typename U>
+using CoarseSolverType = pmg_amd::acc::AmgSolver<acc::Vector<U, acc::Device::HIP>>;
+
+namespace
+{
+/// What `V[i]->element()->basix_element()` of the reference reaches: the degree.
+struct Element
+{
+  pmg_amd::LagrangeElement e;
+  const pmg_amd::LagrangeElement& basix_element() const { return e; }
+};
+struct Space
+{
+  std::shared_ptr<Element> el;
+  examples::PartitionLevel lv;
+  std::shared_ptr<Element> element() const { return el; }
+};
+
+struct Options
+{
+  int n = 64, cheb_its = 3, cycles = 10, amg_cycles = 0, rank = 0;
+  std::array<int, 3> ranks = {1, 1, 1};
+  std::vector<int> orders = {1, 2, 4};
+  bool pcg = false, coarse_cg = false, use_amg = false, random_rhs = false, native_comm = false;
+  std::string id_file = "/tmp/pmg_amd_comm_id", output;
+};
+
+int env_int(std::initializer_list<const char*> names, int fallback)
+{
+  for (const char* nm : names)
+    if (const char* v = std::getenv(nm))
+      return std::atoi(v);
+  return fallback;
+}
+
+std::array<int, 3> parse3(const char* s)
+{
+  std::array<int, 3> r = {1, 1, 1};
+  if (std::sscanf(s, "%d,%d,%d", &r[0], &r[1], &r[2]) != 3 || r[0] < 1 || r[1] < 1 || r[2] < 1)
+    throw std::runtime_error("expected px,py,pz");
+  return r;
+}
+
+std::shared_ptr<const pmg_amd::Communicator> bootstrap(const Options& o, int size)
+{
+  std::array<char, PMG_COMM_ID_BYTES> id{};
+  if (o.rank == 0)
+  {
+    id = pmg_amd::Communicator::unique_id();
+    const std::string tmp = o.id_file + ".tmp";
+    {
+      std::ofstream f(tmp, std::ios::binary);
+      f.write(id.data(), id.size());
+    }
+    std::rename(tmp.c_str(), o.id_file.c_str()); // atomic: readers never see a partial id
+  }
+  else
+  {
+    for (int tries = 0;; ++tries)
+    {
+      std::ifstream f(o.id_file, std::ios::binary);
+      if (f && f.read(id.data(), id.size()))
+        break;
+      if (tries > 600)
+        throw std::runtime_error("timed out waiting for the communicator id in " + o.id_file);
+      std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+  }
+  return std::make_shared<const pmg_amd::Communicator>(o.rank, size, id);
+}
+
+template <typename FineOperator>
+void solve(const Options& o)
+{
+  const int size = o.ranks[0] * o.ranks[1] * o.ranks[2];
+  const bool root = o.rank == 0;
+  const std::vector<int>& order = o.orders;
+  const T kappa = 2.0; // :190-193
+
+  std::shared_ptr<const pmg_amd::Communicator> comm;
+  if (size > 1 || o.native_comm)
+    comm = bootstrap(o, size);
+
+  examples::BrickPartition mesh(o.n, o.ranks, o.rank);
+  device_array<T> constants(std::vector<T>(mesh.ncells, kappa));
+  device_array<T> geom_x_d(mesh.xgeom);
+  device_array<std::int32_t> geom_x_dofmap_d(mesh.geom_dofmap);
+  std::span<const T> device_constants = constants.span(), geom_x = geom_x_d.span();
+  std::span<const std::int32_t> geom_x_dofmap = geom_x_dofmap_d.span();
+
+  // function spaces, index maps, device copies of the dofmaps and Dirichlet markers (:83-257)
+  std::vector<std::shared_ptr<Space>> V(order.size());
+  std::vector<std::shared_ptr<const common::IndexMap>> maps(V.size());
+  std::vector<device_array<std::int32_t>> dofmaps_d(V.size());
+  std::vector<device_array<std::int8_t>> bc_markers_d(V.size());
+  std::vector<std::span<const std::int32_t>> device_dofmaps(V.size());
+  std::vector<std::span<const std::int8_t>> bc_marker_d_span(V.size());
+  std::vector<std::span<const T>> geometry_dphi_d_span(V.size()), Gweights_d_span(V.size()); // from the degree
+  std::vector<int> lcells, bcells; // src/mesh.hpp:105-143; the same split on every level
+  for (std::size_t i = 0; i < V.size(); i++)
+  {
+    const int P = order[i], nd = P + 1;
+    std::vector<double> gll(nd), w(nd);
+    check(pmg_gll_table(nd, gll.data(), w.data()));
+    V[i] = std::make_shared<Space>(Space{std::make_shared<Element>(Element{{P}}), mesh.level(P, gll)});
+    const examples::PartitionLevel& lv = V[i]->lv;
+    if (comm)
+      maps[i] = std::make_shared<const common::IndexMap>(lv.size_local, lv.num_ghosts, lv.send_indices,
+                                                         lv.recv_indices, comm, lv.neighbors, lv.send_counts,
+                                                         lv.recv_counts);
+    else
+      maps[i] = std::make_shared<const common::IndexMap>(lv.size_local, lv.num_ghosts);
+    if (i == V.size() - 1) // :97 (finest space)
+      std::tie(lcells, bcells) = pmg_amd::compute_boundary_cells(lv.dofmap, mesh.ncells_owned, mesh.ncells,
+                                                                 nd * nd * nd, lv.size_local);
+    dofmaps_d[i].assign(lv.dofmap);
+    bc_markers_d[i].assign(lv.bc_marker);
+    device_dofmaps[i] = dofmaps_d[i].span();
+    bc_marker_d_span[i] = bc_markers_d[i].span();
+    if (root)
+      std::printf("Level %zu: degree %d, %lld dofs (rank 0: %d owned + %d ghosts, %zu neighbours)\n", i, P,
+                  (long long)mesh.global_ndofs(P), lv.size_local, lv.num_ghosts, lv.neighbors.size());
+  }
+
+  std::vector<std::shared_ptr<FineOperator>> operators(V.size());
+  std::vector<std::shared_ptr<DeviceVector>> bs(V.size());
+  for (std::size_t i = 0; i < V.size(); i++)
+  {
+    operators[i] = std::make_shared<acc::MatFreeLaplacian<T>>(
+        order[i], device_constants, device_dofmaps[i], geom_x, geom_x_dofmap, geometry_dphi_d_span[i],
+        Gweights_d_span[i], lcells, bcells, bc_marker_d_span[i]); // :270-272
+    operators[i]->compute_diag_inverse(maps[i]);                  // replaces :274-279 (no CSR)
+
+    const examples::PartitionLevel& lv = V[i]->lv;
+    std::vector<T> fh(lv.ndofs());
+    const double pi = M_PI, c2 = (4.0 + 9.0 + 16.0) * pi * pi;
+    for (std::int32_t d = 0; d < lv.ndofs(); ++d)
+      fh[d] = c2 * std::sin(2 * pi * lv.x[3 * d]) * std::sin(3 * pi * lv.x[3 * d + 1]) * std::sin(4 * pi * lv.x[3 * d + 2]);
+    DeviceVector f(maps[i], 1);
+    hip_check(hipMemcpy(f.mutable_array().data(), fh.data(), sizeof(T) * fh.size(), hipMemcpyHostToDevice), "H2D");
+    bs[i] = std::make_shared<DeviceVector>(maps[i], 1);
+    operators[i]->assemble_rhs(f, *bs[i]); // :289-300
+  }
+
+  // ---------------------------------------------------------------------------------------------
+  // From here to the end of the cycle loop: examples/pmg/main.cpp:303-367 (logging calls dropped,
+  // Chebyshev degree and cycle count from the command line).
+
+  // Create chebyshev smoother for each level
+  std::vector<std::shared_ptr<acc::Chebyshev<DeviceVector>>> smoothers(V.size());
+  for (std::size_t i = 0; i < V.size(); i++)
+  {
+    dolfinx::acc::CGSolver<DeviceVector> cg(maps[i], 1);
+    cg.set_max_iterations(20);
+    cg.set_tolerance(1e-6);
+    cg.store_coefficients(true);
+
+    DeviceVector x(maps[i], 1);
+
+    x.set(T{0.0});
+    DeviceVector y(maps[i], 1);
+    y.set(T{1.0});
+
+    [[maybe_unused]] int its = cg.solve(*operators[i], x, y, false);
+    std::vector<T> eign = cg.compute_eigenvalues();
+    std::sort(eign.begin(), eign.end());
+    if (root)
+      std::printf("Eigenvalues level %zu: %.17g - %.17g\n", i, eign.front(), eign.back());
+    std::array<T, 2> eig_range = {0.1 * eign.back(), 1.1 * eign.back()};
+    smoothers[i] = std::make_shared<acc::Chebyshev<DeviceVector>>(maps[i], 1, eig_range);
+    smoothers[i]->set_max_iterations(o.cheb_its);
+  }
+
+  // Create Matrix-Free Interpolators
+  std::vector<std::shared_ptr<Interpolator<T>>> matfree_interpolators(V.size() - 1);
+
+  for (int i = 0; i < (int)V.size() - 1; ++i)
+  {
+    matfree_interpolators[i] = std::make_shared<Interpolator<T>>(
+        V[i]->element()->basix_element(), V[i + 1]->element()->basix_element(), device_dofmaps[i],
+        device_dofmaps[i + 1], lcells, bcells);
+  }
+
+  std::shared_ptr<CoarseSolverType<T>> coarse_solver; // :331-335
+  if (o.use_amg)
+  {
+    auto t0 = std::chrono::steady_clock::now();
+    coarse_solver = std::make_shared<CoarseSolverType<T>>(*operators[0], maps[0]);
+    if (o.amg_cycles > 0)
+      coarse_solver->set_cycles(o.amg_cycles);
+    if (root)
+      std::printf("AMG coarse solver: %d levels, set-up %.2f s, %s\n", coarse_solver->num_levels(),
+                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(),
+                  o.amg_cycles > 0 ? "stationary cycles" : "CG <= 60 iterations, rtol 1e-5");
+  }
+
+  using SolverType = acc::Chebyshev<DeviceVector>;
+  using PMG = acc::MultigridPreconditioner<DeviceVector, FineOperator, SolverType, CoarseSolverType<T>,
+                                           Interpolator<T>>;
+
+  PMG pmg(maps, 1, bc_marker_d_span[0]);
+  pmg.set_solvers(smoothers);
+  pmg.set_operators(operators);
+  pmg.set_coarse_solver(coarse_solver);
+
+  // Sets matrix-free kernels to do interpolation
+  pmg.set_interpolators(matfree_interpolators);
+
+  std::shared_ptr<dolfinx::acc::CGSolver<DeviceVector>> coarse_cg;
+  if (o.coarse_cg && !o.use_amg) // a second coarse-solver type through the C ABI's native CG hook
+  {
+    coarse_cg = std::make_shared<dolfinx::acc::CGSolver<DeviceVector>>(maps[0], 1);
+    coarse_cg->set_max_iterations(60);
+    coarse_cg->set_tolerance(1e-5);
+    check(pmg_multigrid_set_coarse_solver(pmg.handle(), coarse_cg->handle()));
+  }
+
+  // Create solution vector
+  DeviceVector x(maps.back(), 1);
+  x.set(T{0.0});
+
+  if (root)
+    std::printf("Norm of b = %.15e\n", acc::norm(*bs.back()));
+  else
+    (void)acc::norm(*bs.back()); // reductions are collective
+  int niter = o.cycles;
+  for (int i = 0; i < niter; i++)
+  {
+    const T rnorm = pmg.apply(*bs.back(), x, true);
+    if (root)
+      std::printf("Cycle %d: residual norm = %.15e\n", i + 1, rnorm);
+  }
+  // ---------------------------------------------------------------------------------------------
+  {
+    const T xn = acc::norm(x);
+    if (root)
+      std::printf("Norm of x = %.15e\n", xn);
+  }
+
+  // timing of the cycle alone (no residual evaluation)
+  hipEvent_t e0, e1;
+  hip_check(hipEventCreate(&e0), "event");
+  hip_check(hipEventCreate(&e1), "event");
+  const int reps = 10;
+  pmg.apply(*bs.back(), x, false);
+  hip_check(hipEventRecord(e0, nullptr), "record");
+  for (int i = 0; i < reps; ++i)
+    pmg.apply(*bs.back(), x, false);
+  hip_check(hipEventRecord(e1, nullptr), "record");
+  hip_check(hipEventSynchronize(e1), "sync");
+  float ms = 0;
+  hip_check(hipEventElapsedTime(&ms, e0, e1), "elapsed");
+  if (root)
+    std::printf("V-cycle: %.3f ms, %.3f GDoF/s\n", ms / reps,
+                (double)mesh.global_ndofs(order.back()) / (ms * 1e-3 / reps) * 1e-9);
+
+  if (o.pcg)
+  {
+    dolfinx::acc::CGSolver<DeviceVector> cg(maps.back(), 1);
+    cg.set_max_iterations(100);
+    cg.set_tolerance(1e-8);
+    // with a Krylov coarse solve inside, the cycle is not a fixed linear operator
+    cg.set_flexible(o.coarse_cg || (o.use_amg && o.amg_cycles == 0));
+    DeviceVector rhs(maps.back(), 1);
+    if (o.random_rhs)
+    {
+      const examples::PartitionLevel& lv = V.back()->lv;
+      std::vector<T> g(lv.ndofs());
+      for (std::int32_t d = 0; d < lv.ndofs(); ++d) // a function of the GLOBAL dof: the same vector on any partition
+      {
+        std::mt19937_64 gen(0x9E3779B97F4A7C15ull ^ (std::uint64_t)lv.local_to_global[d]);
+        g[d] = lv.bc_marker[d] ? 0.0 : std::normal_distribution<T>()(gen);
+      }
+      hip_check(hipMemcpy(rhs.mutable_array().data(), g.data(), sizeof(T) * g.size(), hipMemcpyHostToDevice), "H2D");
+    }
+    else
+      acc::copy(rhs, *bs.back());
+    x.set(0.0);
+    const int its = cg.solve(*operators.back(), x, rhs, pmg, false);
+    DeviceVector Ax(maps.back(), 1), r(maps.back(), 1);
+    (*operators.back())(x, Ax);
+    acc::axpy(r, -1.0, Ax, rhs); // r = b - A x
+    const T rn = acc::norm(r), bn = acc::norm(rhs), xn = acc::norm(x);
+    if (root)
+      std::printf("PCG with V-cycle preconditioner: %d iterations, |b - A x| / |b| = %.3e, Norm of x = %.15e\n", its,
+                  rn / bn, xn);
+  }
+
+  if (!o.output.empty()) // :369-379 (VTX there; here the fine-level points of this rank as legacy VTK)
+  {
+    const examples::PartitionLevel& lv = V.back()->lv;
+    auto xv = x.thrust_vector(); // :373
+    std::vector<T> u(xv.size());
+    thrust::copy(xv.begin(), xv.end(), u.begin()); // :374
+    const std::string name = size > 1 ? o.output + "." + std::to_string(o.rank) : o.output;
+    std::ofstream f(name);
+    f << "# vtk DataFile Version 3.0\npmg_amd solution, degree " << order.back() << "\nASCII\nDATASET POLYDATA\nPOINTS "
+      << lv.size_local << " double\n";
+    f.precision(17);
+    for (std::int32_t d = 0; d < lv.size_local; ++d)
+      f << lv.x[3 * d] << " " << lv.x[3 * d + 1] << " " << lv.x[3 * d + 2] << "\n";
+    f << "POINT_DATA " << lv.size_local << "\nSCALARS u double 1\nLOOKUP_TABLE default\n";
+    for (std::int32_t d = 0; d < lv.size_local; ++d)
+      f << u[d] << "\n";
+    if (root)
+      std::printf("Solution written to %s\n", name.c_str());
+  }
+}
+} // namespace
 
 int main(int argc, char** argv)
 {
-  int n = 64, cheb_its = 3, cycles = 10;
+  Options o;
   std::size_t ndofs = 0;
-  std::vector<int> orders = {1, 2, 4};
-  bool pcg = false, coarse_cg = false;
-  for (int i = 1; i < argc; ++i)
-  {
-    auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
-    if (!std::strcmp(argv[i], "--n"))
-      n = std::atoi(next());
-    else if (!std::strcmp(argv[i], "--ndofs"))
-      ndofs = std::strtoull(next(), nullptr, 10);
-    else if (!std::strcmp(argv[i], "--orders"))
-    {
-      orders.clear();
-      std::stringstream ss(next());
-      for (std::string tok; std::getline(ss, tok, ',');)
-        orders.push_back(std::atoi(tok.c_str()));
-    }
-    else if (!std::strcmp(argv[i], "--smoother-its"))
-      cheb_its = std::atoi(next());
-    else if (!std::strcmp(argv[i], "--cycles"))
-      cycles = std::atoi(next());
-    else if (!std::strcmp(argv[i], "--pcg"))
-      pcg = true;
-    else if (!std::strcmp(argv[i], "--coarse-cg"))
-      coarse_cg = true;
-    else
-    {
-      std::cout << "usage: pmg [--n cells_per_direction | --ndofs N] [--orders 1,2,4] [--smoother-its K] "
-                   "[--cycles C] [--pcg] [--coarse-cg]\n";
-      return !std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h") ? 0 : 2;
-    }
-  }
+  std::string check_dims;
+  o.rank = env_int({"RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK"}, 0);
   try
   {
-    if (orders.empty() || !std::is_sorted(orders.begin(), orders.end())
-        || std::adjacent_find(orders.begin(), orders.end()) != orders.end())
+    for (int i = 1; i < argc; ++i)
+    {
+      auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
+      if (!std::strcmp(argv[i], "--n"))
+        o.n = std::atoi(next());
+      else if (!std::strcmp(argv[i], "--ndofs")) // dofs per rank, like the reference (:412-435)
+        ndofs = std::strtoull(next(), nullptr, 10);
+      else if (!std::strcmp(argv[i], "--orders"))
+      {
+        o.orders.clear();
+        std::stringstream ss(next());
+        for (std::string tok; std::getline(ss, tok, ',');)
+          o.orders.push_back(std::atoi(tok.c_str()));
+      }
+      else if (!std::strcmp(argv[i], "--smoother-its"))
+        o.cheb_its = std::atoi(next());
+      else if (!std::strcmp(argv[i], "--cycles"))
+        o.cycles = std::atoi(next());
+      else if (!std::strcmp(argv[i], "--pcg"))
+        o.pcg = true;
+      else if (!std::strcmp(argv[i], "--random-rhs"))
+        o.random_rhs = true;
+      else if (!std::strcmp(argv[i], "--coarse-cg"))
+        o.coarse_cg = true;
+      else if (!std::strcmp(argv[i], "--amg"))
+        o.use_amg = true;
+      else if (!std::strcmp(argv[i], "--amg-cycles"))
+      {
+        o.use_amg = true;
+        o.amg_cycles = std::atoi(next());
+      }
+      else if (!std::strcmp(argv[i], "--ranks"))
+        o.ranks = parse3(next());
+      else if (!std::strcmp(argv[i], "--rank"))
+        o.rank = std::atoi(next());
+      else if (!std::strcmp(argv[i], "--native-comm")) // one rank through the RCCL communicator anyway
+        o.native_comm = true;
+      else if (!std::strcmp(argv[i], "--id-file"))
+        o.id_file = next();
+      else if (!std::strcmp(argv[i], "--output"))
+        o.output = next();
+      else if (!std::strcmp(argv[i], "--check-partition"))
+        check_dims = next();
+      else
+      {
+        std::cout << "usage: pmg [--n cells_per_direction | --ndofs N_per_rank] [--orders 1,2,4] [--smoother-its K]\n"
+                     "           [--cycles C] [--pcg [--random-rhs]] [--amg | --amg-cycles N | --coarse-cg]\n"
+                     "           [--ranks px,py,pz [--rank r] [--id-file F]] [--native-comm] [--output FILE]\n"
+                     "           [--check-partition px,py,pz]\n";
+        return !std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h") ? 0 : 2;
+      }
+    }
+    if (o.orders.empty() || !std::is_sorted(o.orders.begin(), o.orders.end())
+        || std::adjacent_find(o.orders.begin(), o.orders.end()) != o.orders.end())
       throw std::runtime_error("--orders must be strictly ascending (coarse to fine)");
-    if (ndofs)
-      n = examples::cells_for_ndofs(ndofs, orders.back());
-    const std::size_t L = orders.size();
-    const double kappa = 2.0; // :190-193
-
-    examples::BoxMesh mesh(n);
-    device_array<double> kappa_d(std::vector<double>(mesh.ncells(), kappa));
-    device_array<double> xgeom(mesh.xgeom);
-    device_array<std::int32_t> xdofmap(mesh.geom_dofmap);
-    std::vector<int> lcells, bcells; // src/mesh.hpp:105-143; the same split on every level
-
-    std::vector<std::shared_ptr<const IndexMap>> maps(L);
-    std::vector<device_array<std::int32_t>> dofmaps(L);
-    std::vector<device_array<std::int8_t>> bc_markers(L);
-    std::vector<std::shared_ptr<acc::MatFreeLaplacian>> operators(L);
-    std::vector<std::shared_ptr<DeviceVector>> bs(L);
-    for (std::size_t i = 0; i < L; ++i)
+    const int size = o.ranks[0] * o.ranks[1] * o.ranks[2];
+    if (ndofs) // cells per direction of the whole mesh so that a rank holds about ndofs fine dofs
+      o.n = examples::cells_for_ndofs(ndofs * (std::size_t)size, o.orders.back());
+    if (!check_dims.empty())
     {
-      const int P = orders[i], nd = P + 1;
-      std::vector<double> gll(nd), w(nd);
-      check(pmg_gll_table(nd, gll.data(), w.data()));
-      examples::FunctionSpace V(mesh, P, gll);
-      std::cout << "Level " << i << ": degree " << P << ", " << V.ndofs << " dofs\n";
-      if (i == 0)
-        std::tie(lcells, bcells) = compute_boundary_cells(V.dofmap, mesh.ncells(), mesh.ncells(), nd * nd * nd, V.ndofs);
-      maps[i] = std::make_shared<const IndexMap>(V.ndofs, 0);
-      dofmaps[i].assign(V.dofmap);
-      bc_markers[i].assign(V.bc_marker);
-      operators[i] = std::make_shared<acc::MatFreeLaplacian>(P, kappa_d.span(), dofmaps[i].span(), xgeom.span(),
-                                                             xdofmap.span(), std::span<const double>{},
-                                                             std::span<const double>{}, lcells, bcells,
-                                                             bc_markers[i].span());
-      operators[i]->compute_diag_inverse(maps[i]);
-
-      std::vector<double> fh(V.ndofs);
-      const double pi = M_PI, c2 = (4.0 + 9.0 + 16.0) * pi * pi;
-      for (std::int32_t d = 0; d < V.ndofs; ++d)
-        fh[d] = c2 * std::sin(2 * pi * V.x[3 * d]) * std::sin(3 * pi * V.x[3 * d + 1])
-                * std::sin(4 * pi * V.x[3 * d + 2]);
-      DeviceVector f(maps[i], 1);
-      f.copy_from_host(fh);
-      bs[i] = std::make_shared<DeviceVector>(maps[i], 1);
-      operators[i]->assemble_rhs(f, *bs[i]);
+      const auto dims = parse3(check_dims.c_str());
+      for (int P : o.orders)
+      {
+        std::vector<double> gll(P + 1), w(P + 1);
+        check(pmg_gll_table(P + 1, gll.data(), w.data()));
+        const std::string err = examples::check_partition(o.n, dims, P, gll);
+        if (!err.empty())
+          throw std::runtime_error("partition check failed at degree " + std::to_string(P) + ": " + err);
+      }
+      std::printf("partition %dx%dx%d of %d^3 cells consistent for every degree\n", dims[0], dims[1], dims[2], o.n);
+      return 0;
     }
-
-    // Chebyshev smoother for each level, :306-330
-    std::vector<std::shared_ptr<acc::Chebyshev<DeviceVector>>> smoothers(L);
-    for (std::size_t i = 0; i < L; ++i)
-    {
-      acc::CGSolver<DeviceVector> cg(maps[i], 1);
-      cg.set_max_iterations(20);
-      cg.set_tolerance(1e-6);
-      cg.store_coefficients(true);
-      DeviceVector x(maps[i], 1), y(maps[i], 1);
-      x.set(0.0);
-      y.set(1.0);
-      [[maybe_unused]] int its = cg.solve(*operators[i], x, y, false);
-      std::vector<double> eign = cg.compute_eigenvalues();
-      std::sort(eign.begin(), eign.end());
-      std::printf("Eigenvalues level %zu: %.17g - %.17g\n", i, eign.front(), eign.back());
-      std::array<double, 2> eig_range = {0.1 * eign.back(), 1.1 * eign.back()};
-      smoothers[i] = std::make_shared<acc::Chebyshev<DeviceVector>>(maps[i], 1, eig_range);
-      smoothers[i]->set_max_iterations(cheb_its);
-    }
-
-    std::vector<std::int32_t> lcells32(lcells.begin(), lcells.end()), bcells32(bcells.begin(), bcells.end());
-    std::vector<std::shared_ptr<Interpolator>> interpolators(L - 1);
-    for (std::size_t i = 0; i + 1 < L; ++i)
-      interpolators[i] = std::make_shared<Interpolator>(orders[i], orders[i + 1], dofmaps[i].span(),
-                                                        dofmaps[i + 1].span(), lcells32, bcells32);
-
-    using PMG = acc::MultigridPreconditioner<DeviceVector, acc::MatFreeLaplacian, Interpolator,
-                                             acc::Chebyshev<DeviceVector>>;
-    PMG pmg(maps, 1, bc_markers[0].span());
-    pmg.set_solvers(smoothers);
-    pmg.set_operators(operators);
-    pmg.set_interpolators(interpolators);
-    if (coarse_cg) // the reference's --amg role (:331-335: KSPCG, 60 iterations; here Jacobi-preconditioned)
-    {
-      auto coarse = std::make_shared<acc::CGSolver<DeviceVector>>(maps[0], 1);
-      coarse->set_max_iterations(60);
-      coarse->set_tolerance(1e-5);
-      pmg.set_coarse_solver(coarse);
-    }
-
-    DeviceVector x(maps.back(), 1);
-    x.set(0.0);
-    std::printf("Norm of b = %.15e\n", acc::norm(*bs.back()));
-    for (int i = 0; i < cycles; ++i)
-    {
-      const double rnorm = pmg.apply(*bs.back(), x, true);
-      std::printf("Cycle %d: residual norm = %.15e\n", i + 1, rnorm);
-    }
-    std::printf("Norm of x = %.15e\n", acc::norm(x));
-
-    // timing of the cycle alone (no residual evaluation)
-    hipEvent_t e0, e1;
-    hip_check(hipEventCreate(&e0), "event");
-    hip_check(hipEventCreate(&e1), "event");
-    const int reps = 10;
-    pmg.apply(*bs.back(), x, false);
-    hip_check(hipEventRecord(e0, nullptr), "record");
-    for (int i = 0; i < reps; ++i)
-      pmg.apply(*bs.back(), x, false);
-    hip_check(hipEventRecord(e1, nullptr), "record");
-    hip_check(hipEventSynchronize(e1), "sync");
-    float ms = 0;
-    hip_check(hipEventElapsedTime(&ms, e0, e1), "elapsed");
-    std::printf("V-cycle: %.3f ms, %.3f GDoF/s\n", ms / reps, maps.back()->size_local() / (ms * 1e-3 / reps) * 1e-9);
-
-    if (pcg)
-    {
-      acc::CGSolver<DeviceVector> cg(maps.back(), 1);
-      cg.set_max_iterations(100);
-      cg.set_tolerance(1e-8);
-      cg.set_flexible(coarse_cg); // the cycle is not a fixed linear operator with a Krylov coarse solve
-      x.set(0.0);
-      const int its = cg.solve(*operators.back(), x, *bs.back(), pmg, false);
-      DeviceVector Ax(maps.back(), 1), r(maps.back(), 1);
-      (*operators.back())(x, Ax);
-      acc::axpy(r, -1.0, Ax, *bs.back()); // r = b - A x
-      std::printf("PCG with V-cycle preconditioner: %d iterations, |b - A x| / |b| = %.3e, Norm of x = %.15e\n", its,
-                  acc::norm(r) / acc::norm(*bs.back()), acc::norm(x));
-    }
+    if (o.rank < 0 || o.rank >= size)
+      throw std::runtime_error("rank out of range for --ranks");
+    int ndev = 0;
+    hip_check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+    if (ndev < 1)
+      throw std::runtime_error("no GPU");
+    hip_check(hipSetDevice(env_int({"LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK"}, o.rank) % ndev), "hipSetDevice");
+    solve<acc::MatFreeLaplacian<T>>(o);
   }
   catch (const std::exception& ex)
   {

@@ -12,6 +12,8 @@
 #include <random>
 
 using namespace pmg_amd;
+using T = double;
+using DeviceVector = acc::Vector<T, acc::Device::HIP>;
 
 static int failures = 0;
 #define CHECK(cond)                                                                                \
@@ -87,7 +89,7 @@ int main()
       v = dist(rng);
     for (auto& v : b)
       v = dist(rng);
-    acc::Vector x(map, 1), y(map, 1), r(map, 1);
+    DeviceVector x(map, 1), y(map, 1), r(map, 1);
     x.copy_from_host(a);
     y.copy_from_host(b);
 
@@ -152,7 +154,7 @@ int main()
     CHECK(got.front() == 1.5 && got.back() == 1.5);
 
     {
-      acc::Vector w(nomax, 1); // several ranks but no max-reduction callback: linf must refuse
+      DeviceVector w(nomax, 1); // several ranks but no max-reduction callback: linf must refuse
       CHECK(throws([&] { acc::norm(w, acc::Norm::linf); }, "allreduce_max"));
     }
 
@@ -163,19 +165,37 @@ int main()
 
     // error behaviour
     auto small = std::make_shared<IndexMap>(10, 0);
-    acc::Vector s(small, 1);
+    DeviceVector s(small, 1);
     CHECK(throws([&] { acc::inner_product(x, s); }, "Incompatible vector sizes"));
-    CHECK(throws([&] { acc::Vector bad(small, 2); }, "block size"));
+    CHECK(throws([&] { DeviceVector bad(small, 2); }, "block size"));
     device_array<double> kap(std::vector<double>(1, 1.0));
     device_array<std::int32_t> dmd(std::vector<std::int32_t>(1000, 0)), gd(std::vector<std::int32_t>(8, 0));
     device_array<double> xg(std::vector<double>(24, 0.0));
     device_array<std::int8_t> bcm(std::vector<std::int8_t>(10, 0));
     CHECK(throws(
         [&] {
-          acc::MatFreeLaplacian op(9, kap.span(), dmd.span(), xg.span(), gd.span(), {}, {}, {0}, {}, bcm.span());
+          acc::MatFreeLaplacian<T> op(9, kap.span(), dmd.span(), xg.span(), gd.span(), {}, {}, {0}, {}, bcm.span());
         },
         "Unsupported degree"));
-    CHECK(throws([&] { Interpolator ip(2, 2, dmd.span(), dmd.span(), {}, {}); }, "degree"));
+    CHECK(throws([&] { Interpolator<T> ip(2, 2, dmd.span(), dmd.span(), {}, {}); }, "degree"));
+    CHECK(throws([&] { Interpolator<T> ip(LagrangeElement{3}, LagrangeElement{2}, dmd.span(), dmd.span(), {}, {}); },
+                 "degree"));
+    // a vector of another map with the same size_local is still another map (different halo plan)
+    auto twin = std::make_shared<IndexMap>(n, 0);
+    DeviceVector tw(twin, 1);
+    CHECK(throws([&] { acc::inner_product(x, tw); }, "Incompatible vector sizes"));
+
+    // acc::transform (src/vector.hpp:449-454) with a device functor, thrust_vector(), copy constructor
+    x.copy_from_host(a);
+    acc::transform(x, [] __host__ __device__(const T& v) { return 2.0 * v + 1.0; });
+    got = x.data_copy();
+    ok = true;
+    for (int i = 0; i < n; ++i)
+      ok = ok && got[i] == 2.0 * a[i] + 1.0;
+    CHECK(ok);
+    CHECK(x.thrust_vector().size() == (std::size_t)(n + m));
+    DeviceVector xc(x);
+    CHECK(xc.data_copy() == x.data_copy() && xc.map() == x.map());
   }
   catch (const std::exception& e)
   {

@@ -45,6 +45,7 @@ typedef struct pmg_chebyshev_s* pmg_chebyshev;
 typedef struct pmg_cg_s* pmg_cg;
 typedef struct pmg_interpolator_s* pmg_interpolator;
 typedef struct pmg_multigrid_s* pmg_multigrid;
+typedef struct pmg_amg_s* pmg_amg;
 
 const char* pmg_last_error(void);
 int pmg_version(void);
@@ -222,6 +223,14 @@ int pmg_laplacian_degree(pmg_laplacian op);
  * separate from storedG).  Fails if the mesh has a non-affine cell. */
 int pmg_laplacian_is_affine(pmg_laplacian op);
 int pmg_laplacian_set_geometry_mode(pmg_laplacian op, int mode);
+/* Geometry batching (src/laplacian.hpp:383-396; examples/mat_free/main.cpp:34-50 --batch_size):
+ * with batch_cells > 0 the tensor G is not kept; every application recomputes it for about
+ * batch_cells cells at a time (rounded up to whole patches) into a buffer of that size, right
+ * before the cells' stiffness launch -- the reference's memory / time trade, bit-identical
+ * results.  0 (default) keeps G resident (288 GB of HBM).  pmg_laplacian_geometry_bytes
+ * returns the size of the tensor buffer currently held. */
+int pmg_laplacian_set_geometry_batch(pmg_laplacian op, long long batch_cells);
+long long pmg_laplacian_geometry_bytes(pmg_laplacian op);
 /* One operator application issues one stiffness-kernel launch per patch colour of the
  * interior cell list (8 on a structured box) plus one for the boundary list; on a small
  * level -- fewer patch dofs in the interior list than 2 M (degree <= 2) / 6 M (degree >= 3) --
@@ -333,6 +342,36 @@ int pmg_multigrid_set_coarse_solver(pmg_multigrid mg, pmg_cg coarse);
  * NULL restores the smoother.  (pmg_amg below is the library's own such solver.) */
 typedef int (*pmg_coarse_solve_fn)(void* user, double* x, double* b, pmg_stream stream);
 int pmg_multigrid_set_coarse_callback(pmg_multigrid mg, pmg_coarse_solve_fn solve, void* user);
+/* ---- algebraic multigrid for the coarsest level (the role of CoarseSolverType<T>, src/amg.hpp) ----
+ * The reference solves its degree-1 level with PETSc KSPCG (<= 60 iterations, default relative
+ * tolerance 1e-5) preconditioned by hypre BoomerAMG (src/amg.hpp:33-47).  Those are third-party;
+ * pmg_amg is the library's own solver for that slot: smoothed-aggregation AMG on the assembled
+ * degree-1 matrix (built on the host from the operator's geometry tensor; cycles run on the device
+ * with the same Chebyshev/Jacobi smoother as the p-levels), used either
+ *   - Krylov mode (default, the reference's shape): CG on the matrix-free operator preconditioned
+ *     by one AMG V-cycle, zero initial guess, max_iter / rtol as set (60, 1e-5); or
+ *   - stationary mode (pmg_amg_set_cycles(n > 0)): n AMG V-cycles from a zero initial guess -- a
+ *     fixed linear operator without host synchronisation (single rank only).
+ * `op` must be a degree-1 operator and outlive the solver.  On several ranks the hierarchy is built
+ * on the rank's own block (ghost couplings dropped from the preconditioner only). */
+int pmg_amg_create(pmg_amg* out, pmg_laplacian op, pmg_stream stream);
+int pmg_amg_destroy(pmg_amg amg);
+int pmg_amg_set_smoother_iterations(pmg_amg amg, int k); /* Chebyshev degree per pre/post smooth (2) */
+int pmg_amg_set_cycles(pmg_amg amg, int cycles);
+int pmg_amg_set_krylov(pmg_amg amg, int max_iter, double rtol);
+/* solve(x, b) of src/amg.hpp:67-68; *iterations = CG iterations (or cycles) used. */
+int pmg_amg_solve(pmg_amg amg, double* x, const double* b, int* iterations, pmg_stream stream);
+/* One V-cycle of the hierarchy from a zero initial guess: x = M b (the preconditioner alone). */
+int pmg_amg_cycle(pmg_amg amg, double* x, const double* b, pmg_stream stream);
+int pmg_amg_num_levels(pmg_amg amg);
+int pmg_amg_level_info(pmg_amg amg, int level, long long* rows, long long* nnz, double* lambda_max);
+/* Host copy of the hierarchy (tests): which = 0 the matrix of `level`, 1 the prolongator from
+ * level + 1 to `level`; CSR.  Call with NULL arrays first to learn the sizes. */
+int pmg_amg_export(pmg_amg amg, int level, int which, long long* rows, long long* cols, long long* nnz,
+                   int32_t* rowptr, int32_t* colidx, double* values);
+/* set_coarse_solver (src/pmg.hpp:46) with the library's AMG; NULL restores the smoother. */
+int pmg_multigrid_set_coarse_amg(pmg_multigrid mg, pmg_amg amg);
+
 /* apply(x = rhs, y = initial guess in / result out, verbose), :56-155.  If
  * rnorm is non-NULL the final residual norm ||b - A y|| is computed (the
  * reference prints it when verbose, :147-150) -- this costs one extra apply and a

@@ -1,29 +1,43 @@
 // pmg_amd.hpp -- C++ adapter over the C ABI of pmg_amd.h.
 //
-// Re-exports the duck-typed concepts the reference's drivers are written
-// against (Wells-Group/pmg-dolfinx @ 2024_08_07):
+// Re-exports the duck-typed concepts the reference's drivers are written against, with
+// the reference's template spellings (Wells-Group/pmg-dolfinx @ 2024_08_07):
 //
-//   acc::Vector                    src/vector.hpp:74-325 (+ free functions :333-454)
-//   acc::MatFreeLaplacian          src/laplacian.hpp:284-526
-//   acc::Chebyshev<Vector>         src/chebyshev.hpp:19-106
-//   acc::CGSolver<Vector>          src/cg.hpp:93-250
-//   Interpolator                   src/interpolate.hpp:93-329
-//   acc::MultigridPreconditioner   src/pmg.hpp:16-184
+//   acc::Device, acc::Vector<T, Device>            src/vector.hpp:61-66, 74-325
+//   acc::inner_product ... acc::transform          src/vector.hpp:333-454
+//   acc::MatFreeLaplacian<T>                       src/laplacian.hpp:284-526
+//   acc::Chebyshev<Vector>                         src/chebyshev.hpp:19-106
+//   acc::CGSolver<Vector>                          src/cg.hpp:93-250
+//   Interpolator<T>                                src/interpolate.hpp:93-329
+//   acc::MultigridPreconditioner<Vector, Operator, Solver, CoarseSolver, Interpolator>
+//                                                  src/pmg.hpp:13-184
 //
-// with the same member names, argument meaning and error behaviour
-// (std::runtime_error), so that examples/pmg/main.cpp:270-365 and
-// examples/mat_free/main.cpp:236-288 read the same on top of it (see
-// examples/ in this repository).  dolfinx is not a dependency: the one dolfinx
-// type on the path, common::IndexMap (+ its Scatterer), is replaced by
-// pmg_amd::IndexMap below, which carries the same information flattened to
-// arrays; INTEGRATION.md shows the constructor a maintainer adds to build it
-// from a dolfinx IndexMap.  Header-only, C++20 (std::span, like the reference),
-// needs the HIP runtime headers; link with libpmg_amd.so and amdhip64.
+// same member names, argument meaning and error behaviour (std::runtime_error), so that
+// examples/pmg/main.cpp:306-365 and examples/mat_free/main.cpp:236-288 compile on top of it
+// as they stand (examples/pmg/pmg_main.cpp in this repository carries those lines).  T is
+// double and Device is HIP: the library is FP64 on gfx950, like the reference's
+// `using T = double` (examples/pmg/main.cpp:30); anything else is a compile-time error.
+//
+// dolfinx is not a dependency.  The one dolfinx type on the path, common::IndexMap (+ its
+// Scatterer), is replaced by pmg_amd::IndexMap, which carries the same information flattened
+// to arrays (INTEGRATION.md shows how a maintainer builds it from a dolfinx IndexMap), and the
+// basix elements the Interpolator is constructed from by anything with a degree() member
+// (basix::FiniteElement has one; pmg_amd::LagrangeElement is the stand-in).  Define
+// PMG_AMD_DOLFINX_NAMESPACE before including this header to get the names under the
+// reference's own namespaces (dolfinx::acc::..., dolfinx::common::IndexMap, ::Interpolator).
+//
+// Header-only, C++20 (std::span, like the reference); compile with hipcc (the vector storage is
+// a thrust::device_vector, exactly as in the reference, so thrust_vector() and acc::transform
+// exist); link with libpmg_amd.so and amdhip64.
 #pragma once
 
 #include "pmg_amd.h"
 
 #include <hip/hip_runtime.h>
+#include <thrust/copy.h>
+#include <thrust/device_vector.h>
+#include <thrust/execution_policy.h>
+#include <thrust/transform.h>
 
 #include <array>
 #include <cstdint>
@@ -31,6 +45,7 @@
 #include <span>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -47,7 +62,7 @@ inline void hip_check(hipError_t e, const char* what)
     throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
-/// Owning device array (the reference uses thrust::device_vector for this).
+/// Owning device array for the drivers' mesh data (dofmaps, coordinates, markers).
 template <typename T>
 class device_array
 {
@@ -105,10 +120,37 @@ private:
   std::size_t _n = 0;
 };
 
+/// One process's handle on the native RCCL communicator (pmg_comm, see pmg_amd.h): the role MPI
+/// plays under dolfinx's Scatterer.  Rank 0 creates the id, every rank constructs from it.
+class Communicator
+{
+public:
+  static std::array<char, PMG_COMM_ID_BYTES> unique_id()
+  {
+    std::array<char, PMG_COMM_ID_BYTES> id{};
+    check(pmg_comm_unique_id(id.data()));
+    return id;
+  }
+  Communicator(int rank, int size, const std::array<char, PMG_COMM_ID_BYTES>& id)
+  {
+    check(pmg_comm_create(&_c, rank, size, id.data()));
+  }
+  Communicator(const Communicator&) = delete;
+  Communicator& operator=(const Communicator&) = delete;
+  ~Communicator() { pmg_comm_destroy(_c); }
+  int rank() const { return pmg_comm_rank(_c); }
+  int size() const { return pmg_comm_size(_c); }
+  pmg_comm handle() const { return _c; }
+
+private:
+  pmg_comm _c = nullptr;
+};
+
 /// Stand-in for dolfinx::common::IndexMap + common::Scatterer on this path:
 /// owned/ghost sizes, the packed index lists of the halo
-/// (Scatterer::local_indices() / remote_indices(), src/vector.hpp:91-92) and the
-/// exchange itself as callbacks (see pmg_amd.h).  Owns the device copies and the
+/// (Scatterer::local_indices() / remote_indices(), src/vector.hpp:91-92) and who moves the
+/// packed buffers: the library's RCCL communicator (second constructor) or the caller's
+/// callbacks (first constructor; MPI).  Owns the device copies and the
 /// staging buffers; every Vector / operator / solver on this map shares them.
 class IndexMap
 {
@@ -125,6 +167,20 @@ public:
     if (allreduce_max)
       check(pmg_layout_set_allreduce_max(_layout, allreduce_max));
   }
+  /// Halo over the native communicator: index lists grouped by neighbour, in the order of
+  /// `neighbors`, with the per-neighbour counts.
+  IndexMap(std::int32_t size_local, std::int32_t num_ghosts, std::span<const std::int32_t> send_indices,
+           std::span<const std::int32_t> recv_indices, std::shared_ptr<const Communicator> comm,
+           std::span<const std::int32_t> neighbors, std::span<const std::int32_t> send_counts,
+           std::span<const std::int32_t> recv_counts)
+      : IndexMap(size_local, num_ghosts, send_indices, recv_indices)
+  {
+    if (neighbors.size() != send_counts.size() || neighbors.size() != recv_counts.size())
+      throw std::runtime_error("IndexMap: neighbour arrays of different lengths");
+    _comm = std::move(comm);
+    check(pmg_layout_set_comm(_layout, _comm->handle(), (std::int32_t)neighbors.size(), neighbors.data(),
+                              send_counts.data(), recv_counts.data()));
+  }
   IndexMap(const IndexMap&) = delete;
   IndexMap& operator=(const IndexMap&) = delete;
   ~IndexMap() { pmg_layout_destroy(_layout); }
@@ -140,6 +196,7 @@ private:
   std::int32_t _size_local, _num_ghosts;
   device_array<std::int32_t> _send_idx, _recv_idx;
   device_array<double> _send, _recv;
+  std::shared_ptr<const Communicator> _comm;
   pmg_layout _layout = nullptr;
 };
 
@@ -164,135 +221,201 @@ compute_boundary_cells(std::span<const std::int32_t> dofmap, std::int32_t ncells
   return {std::move(local_cells), std::move(boundary_cells)};
 }
 
+/// What the Interpolator needs to know about a basix GLL Lagrange element: its degree.
+struct LagrangeElement
+{
+  int p;
+  int degree() const { return p; }
+};
+
 namespace acc
 {
+/// src/vector.hpp:61-66.  Only HIP exists here.
+enum class Device
+{
+  CUDA,
+  HIP,
+  CPP
+};
+
 enum class Norm
 {
   l2,
   linf
 };
 
-/// acc::Vector<double, Device::HIP> (src/vector.hpp:74-325), block size 1.
+/// acc::Vector<T, Device> (src/vector.hpp:74-325), block size 1.
+template <typename T, Device D>
 class Vector
 {
+  static_assert(std::is_same_v<T, double>, "pmg_amd: the library computes in double (examples/pmg/main.cpp:30)");
+  static_assert(D == Device::HIP, "pmg_amd: gfx950 only -- use acc::Device::HIP");
+
 public:
-  using value_type = double;
+  using value_type = T;
+  constexpr static Device device = D;
 
   Vector(std::shared_ptr<const IndexMap> map, int bs) : _map(std::move(map))
   {
     if (bs != 1)
       throw std::runtime_error("Vector: block size must be 1");
-    _x.resize((std::size_t)_map->size_local() + _map->num_ghosts()); // zero-initialised, :88
+    _x = thrust::device_vector<T>((std::size_t)_map->size_local() + _map->num_ghosts(), T(0)); // :88
   }
+  Vector(const Vector& x) = default; // :99 (the halo plan lives in the map, so nothing is lost)
   Vector(Vector&&) = default;
-  Vector& operator=(Vector&&) = default;
+  Vector& operator=(const Vector& x) = delete; // :102
+  Vector& operator=(Vector&& x) = default;     // :105
 
-  void set(double v) { check(pmg_vec_set(_map->layout(), _x.data(), v, nullptr)); } // :109-115
-  /// Owned part from a host array (:120-128).
-  void copy_from_host(std::span<const double> host)
+  void set(T v) { check(pmg_vec_set(_map->layout(), data(), v, nullptr)); } // :109-115
+  /// Owned part from a host container with array() (la::Vector) or a contiguous range (:117-122).
+  template <typename OtherVector>
+  void copy_from_host(const OtherVector& other)
   {
-    if ((std::int32_t)host.size() < _map->size_local())
+    const T* src;
+    std::size_t n;
+    if constexpr (requires { other.array(); })
+    {
+      src = other.array().data();
+      n = other.array().size();
+    }
+    else
+    {
+      src = std::data(other);
+      n = std::size(other);
+    }
+    if (n < (std::size_t)_map->size_local())
       throw std::runtime_error("copy_from_host: source shorter than size_local");
-    hip_check(hipMemcpy(_x.data(), host.data(), sizeof(double) * _map->size_local(), hipMemcpyHostToDevice),
-              "hipMemcpy H2D");
+    hip_check(hipMemcpy(data(), src, sizeof(T) * _map->size_local(), hipMemcpyHostToDevice), "hipMemcpy H2D");
   }
-  std::shared_ptr<const IndexMap> map() const { return _map; }
-  constexpr int bs() const { return 1; }
-  std::span<const double> array() const { return _x.span(); }
-  std::span<double> mutable_array() { return _x.span(); }
+  template <typename OtherVector>
+  void copy(OtherVector& other) // :124-129
+  {
+    _x.resize(other.array().size());
+    thrust::copy(other.array().begin(), other.array().end(), _x.begin());
+  }
+  std::shared_ptr<const IndexMap> map() const { return _map; }                    // :132
+  constexpr int bs() const { return 1; }                                          // :135
+  thrust::device_vector<T>& thrust_vector() { return _x; }                        // :138
+  std::span<const T> array() const { return {thrust::raw_pointer_cast(_x.data()), _x.size()}; } // :141-150
+  std::span<T> mutable_array() { return {thrust::raw_pointer_cast(_x.data()), _x.size()}; }     // :153-162
   /// Host copy of owned + ghost entries (data_copy(), :296-302).
-  std::vector<double> data_copy() const { return _x.to_host(); }
+  std::vector<T> data_copy() const
+  {
+    std::vector<T> h(_x.size());
+    thrust::copy(_x.begin(), _x.end(), h.begin());
+    return h;
+  }
 
-  void scatter_fwd_begin() { check(pmg_scatter_fwd_begin(_map->layout(), _x.data(), nullptr)); } // :186-207
-  void scatter_fwd_end() { check(pmg_scatter_fwd_end(_map->layout(), _x.data(), nullptr)); }     // :213-238
-  void scatter_fwd()
+  void scatter_fwd_begin() { check(pmg_scatter_fwd_begin(_map->layout(), data(), nullptr)); } // :186-207
+  void scatter_fwd_end() { check(pmg_scatter_fwd_end(_map->layout(), data(), nullptr)); }     // :213-238
+  void scatter_fwd()                                                                          // :242-246
   {
     scatter_fwd_begin();
     scatter_fwd_end();
   }
-  void scatter_rev_begin() { check(pmg_scatter_rev_begin(_map->layout(), _x.data(), nullptr)); } // :249-263
-  void scatter_rev_end() { check(pmg_scatter_rev_end(_map->layout(), _x.data(), nullptr)); }     // :271-286
+  void scatter_rev_begin() { check(pmg_scatter_rev_begin(_map->layout(), data(), nullptr)); } // :249-263
+  void scatter_rev_end() { check(pmg_scatter_rev_end(_map->layout(), data(), nullptr)); }     // :271-286
 
 private:
+  T* data() { return thrust::raw_pointer_cast(_x.data()); }
   std::shared_ptr<const IndexMap> _map;
-  device_array<double> _x;
+  thrust::device_vector<T> _x;
 };
 
-inline void require_same_map(const Vector& a, const Vector& b)
+/// Two vectors are compatible when they share the halo plan, i.e. the same pmg_layout: equal
+/// size_local alone would let an operator run one map's pack / unpack lists on another's storage.
+template <typename V1, typename V2>
+inline void require_same_map(const V1& a, const V2& b)
 {
-  if (a.map()->size_local() != b.map()->size_local())
+  if (a.map()->layout() != b.map()->layout())
     throw std::runtime_error("Incompatible vector sizes"); // src/vector.hpp:343
 }
 
 // Free functions of src/vector.hpp:333-454.
-inline double inner_product(const Vector& a, const Vector& b)
+template <typename Vector>
+auto inner_product(const Vector& a, const Vector& b)
 {
   require_same_map(a, b);
   double r = 0;
   check(pmg_vec_inner_product(a.map()->layout(), a.array().data(), b.array().data(), &r, nullptr));
   return r;
 }
-inline double squared_norm(const Vector& a)
+template <typename Vector>
+auto squared_norm(const Vector& a)
 {
   double r = 0;
   check(pmg_vec_squared_norm(a.map()->layout(), a.array().data(), &r, nullptr));
   return r;
 }
-inline double norm(const Vector& a, Norm type = Norm::l2)
+template <typename Vector>
+auto norm(const Vector& a, Norm type = Norm::l2)
 {
   double r = 0;
   check(pmg_vec_norm(a.map()->layout(), a.array().data(), type == Norm::l2 ? 0 : 1, &r, nullptr));
   return r;
 }
 /// r = alpha * x + y
-inline void axpy(Vector& r, double alpha, const Vector& x, const Vector& y)
+template <typename Vector, typename S>
+void axpy(Vector& r, S alpha, const Vector& x, const Vector& y)
 {
   require_same_map(x, y);
-  check(pmg_vec_axpy(r.map()->layout(), r.mutable_array().data(), alpha, x.array().data(), y.array().data(),
+  require_same_map(r, x);
+  check(pmg_vec_axpy(r.map()->layout(), r.mutable_array().data(), (double)alpha, x.array().data(), y.array().data(),
                      nullptr));
 }
-inline void scale(Vector& r, double alpha)
+template <typename Vector, typename S>
+void scale(Vector& r, S alpha)
 {
-  check(pmg_vec_scale(r.map()->layout(), r.mutable_array().data(), alpha, nullptr));
+  check(pmg_vec_scale(r.map()->layout(), r.mutable_array().data(), (double)alpha, nullptr));
 }
-/// b = a
-inline void copy(Vector& b, const Vector& a)
+/// a = b
+template <typename Vector>
+void copy(Vector& a, const Vector& b)
 {
   require_same_map(a, b);
-  check(pmg_vec_copy(b.map()->layout(), b.mutable_array().data(), a.array().data(), nullptr));
+  check(pmg_vec_copy(a.map()->layout(), a.mutable_array().data(), b.array().data(), nullptr));
 }
 /// w = x .* y
-inline void pointwise_mult(Vector& w, const Vector& x, const Vector& y)
+template <typename Vector>
+void pointwise_mult(Vector& w, const Vector& x, const Vector& y)
 {
   require_same_map(x, y);
+  require_same_map(w, x);
   check(pmg_vec_pointwise_mult(w.map()->layout(), w.mutable_array().data(), x.array().data(), y.array().data(),
                                nullptr));
 }
+/// x_i = op(x_i) on the owned entries, any device functor (:449-454).
+template <typename Vector, typename UnaryFunction>
+void transform(Vector& x, UnaryFunction op)
+{
+  auto& v = x.thrust_vector();
+  thrust::transform(thrust::device, v.begin(), v.begin() + x.map()->size_local(), v.begin(), op);
+}
 
-/// acc::MatFreeLaplacian<double> (src/laplacian.hpp:284-526).  The spans are
+/// acc::MatFreeLaplacian<T> (src/laplacian.hpp:284-526).  The spans are
 /// device memory owned by the caller and must outlive the operator (:500-509).
+template <typename T>
 class MatFreeLaplacian
 {
+  static_assert(std::is_same_v<T, double>, "pmg_amd: the library computes in double");
+
 public:
-  using value_type = double;
+  using value_type = T;
 
   /// Argument list of the reference (:289-297).  dphi_geometry and G_weights may be
   /// empty: both follow from the degree.  The handle is created with the first
   /// vector (or index map) the operator sees, because the reference's operator
   /// borrows the halo of its input vector (:378,425).
-  MatFreeLaplacian(int degree, std::span<const double> coefficients, std::span<const std::int32_t> dofmap,
-                   std::span<const double> xgeom, std::span<const std::int32_t> geometry_dofmap,
-                   std::span<const double> dphi_geometry, std::span<const double> G_weights,
-                   const std::vector<int>& lcells, const std::vector<int>& bcells,
-                   std::span<const std::int8_t> bc_marker, std::size_t batch_size = 0)
+  MatFreeLaplacian(int degree, std::span<const T> coefficients, std::span<const std::int32_t> dofmap,
+                   std::span<const T> xgeom, std::span<const std::int32_t> geometry_dofmap,
+                   std::span<const T> dphi_geometry, std::span<const T> G_weights, const std::vector<int>& lcells,
+                   const std::vector<int>& bcells, std::span<const std::int8_t> bc_marker, std::size_t batch_size = 0)
       : _degree(degree), _kappa(coefficients), _dofmap(dofmap), _xgeom(xgeom), _geom_dofmap(geometry_dofmap),
         _dphi(dphi_geometry), _gw(G_weights), _lcells(lcells.begin(), lcells.end()),
-        _bcells(bcells.begin(), bcells.end()), _bc(bc_marker)
+        _bcells(bcells.begin(), bcells.end()), _bc(bc_marker), _batch_size(batch_size)
   {
     if (degree < 1 || degree > PMG_MAX_DEGREE)
       throw std::runtime_error("Unsupported degree [mat-free operator]"); // :346
-    if (batch_size != 0)
-      throw std::runtime_error("MatFreeLaplacian: geometry batching is not supported (G stays resident)");
     const std::size_t N = (std::size_t)(degree + 1) * (degree + 1) * (degree + 1);
     if (dofmap.size() % N != 0 || dofmap.size() / N != coefficients.size()
         || geometry_dofmap.size() != 8 * coefficients.size())
@@ -307,14 +430,18 @@ public:
   }
 
   /// out = A in (:462-482): zeroes out, updates the ghosts of in.
+  template <typename Vector>
   void operator()(Vector& in, Vector& out)
   {
+    require_same_map(in, out);
     check(pmg_laplacian_apply(handle(in.map()), in.mutable_array().data(), out.mutable_array().data(), nullptr));
   }
+  template <typename Vector>
   void get_diag_inverse(Vector& diag_inv) // :484-489
   {
     check(pmg_laplacian_get_diag_inverse(handle(diag_inv.map()), diag_inv.mutable_array().data(), nullptr));
   }
+  template <typename Vector>
   void set_diag_inverse(const Vector& diag_inv) // :491-495
   {
     check(pmg_laplacian_set_diag_inverse(handle(diag_inv.map()), diag_inv.array().data(), nullptr));
@@ -326,8 +453,10 @@ public:
   }
   /// b = GLL-collocated load vector of the nodal source f, BC rows zeroed
   /// (assemble_vector + set_bc, examples/pmg/main.cpp:289-300).
+  template <typename Vector>
   void assemble_rhs(const Vector& f, Vector& b)
   {
+    require_same_map(f, b);
     check(pmg_laplacian_assemble_rhs(handle(f.map()), f.array().data(), b.mutable_array().data(), nullptr));
   }
   int degree() const { return _degree; }
@@ -349,32 +478,37 @@ public:
                                    _dofmap.data(), _xgeom.data(), (std::int32_t)(_xgeom.size() / 3),
                                    _geom_dofmap.data(), _lcells.data(), (std::int32_t)_lcells.size(),
                                    _bcells.data(), (std::int32_t)_bcells.size(), _bc.data(), nullptr));
+      if (_batch_size != 0) // :383-396: the geometry tensor is not kept, it is recomputed batch by batch
+        check(pmg_laplacian_set_geometry_batch(_op, (long long)_batch_size));
       _map = map;
     }
-    else if (map.get() != _map.get() && map->size_local() != _map->size_local())
+    else if (map->layout() != _map->layout())
       throw std::runtime_error("MatFreeLaplacian: vector lives on a different index map");
     return _op;
   }
 
 private:
   int _degree;
-  std::span<const double> _kappa;
+  std::span<const T> _kappa;
   std::span<const std::int32_t> _dofmap;
-  std::span<const double> _xgeom;
+  std::span<const T> _xgeom;
   std::span<const std::int32_t> _geom_dofmap;
-  std::span<const double> _dphi, _gw;
+  std::span<const T> _dphi, _gw;
   std::vector<std::int32_t> _lcells, _bcells;
   std::span<const std::int8_t> _bc;
+  std::size_t _batch_size;
   std::shared_ptr<const IndexMap> _map;
   pmg_laplacian _op = nullptr;
 };
 
 /// acc::Chebyshev<Vector> (src/chebyshev.hpp:19-106).
-template <typename V = Vector>
+template <typename Vector>
 class Chebyshev
 {
+  using T = typename Vector::value_type;
+
 public:
-  Chebyshev(std::shared_ptr<const IndexMap> map, int /*bs*/, std::array<double, 2> eig_range) : _map(std::move(map))
+  Chebyshev(std::shared_ptr<const IndexMap> map, int /*bs*/, std::array<T, 2> eig_range) : _map(std::move(map))
   {
     check(pmg_chebyshev_create(&_s, _map->layout(), eig_range[0], eig_range[1]));
   }
@@ -383,7 +517,7 @@ public:
   ~Chebyshev() { pmg_chebyshev_destroy(_s); }
   void set_max_iterations(int n) { check(pmg_chebyshev_set_max_iterations(_s, n)); } // :40
   template <typename Operator>
-  void solve(Operator& A, V& x, const V& b, bool /*verbose*/ = false) // :46-91
+  void solve(Operator& A, Vector& x, const Vector& b, bool /*verbose*/ = false) // :46-91
   {
     check(pmg_chebyshev_solve(_s, A.handle(x.map()), x.mutable_array().data(), b.array().data(), nullptr));
   }
@@ -394,13 +528,12 @@ private:
   pmg_chebyshev _s = nullptr;
 };
 
-template <typename V, typename Operator, typename Interp, typename Solver>
-class MultigridPreconditioner;
-
 /// acc::CGSolver<Vector> (src/cg.hpp:93-250).
-template <typename V = Vector>
+template <typename Vector>
 class CGSolver
 {
+  using T = typename Vector::value_type;
+
 public:
   CGSolver(std::shared_ptr<const IndexMap> map, int /*bs*/) : _map(std::move(map))
   {
@@ -416,7 +549,7 @@ public:
   void set_flexible(bool flag) { check(pmg_cg_set_flexible(_s, flag ? 1 : 0)); }
   /// Jacobi-preconditioned CG (:147-222); returns the iteration count.
   template <typename Operator>
-  int solve(Operator& A, V& x, const V& b, bool /*verbose*/ = false)
+  int solve(Operator& A, Vector& x, const Vector& b, bool /*verbose*/ = false)
   {
     int its = 0;
     check(pmg_cg_solve(_s, A.handle(x.map()), x.mutable_array().data(), b.array().data(), nullptr, &its, nullptr));
@@ -424,26 +557,27 @@ public:
   }
   /// CG preconditioned by one V-cycle per iteration (BASELINE config 2; not in the reference).
   template <typename Operator, typename MG>
-  int solve(Operator& A, V& x, const V& b, MG& precond, bool /*verbose*/ = false)
+    requires requires(MG& m) { m.handle(); }
+  int solve(Operator& A, Vector& x, const Vector& b, MG& precond, bool /*verbose*/ = false)
   {
     int its = 0;
     check(pmg_cg_solve(_s, A.handle(x.map()), x.mutable_array().data(), b.array().data(), precond.handle(), &its,
                        nullptr));
     return its;
   }
-  std::vector<double> alphas() const { return coefficients().first; } // :118
-  std::vector<double> betas() const { return coefficients().second; } // :119
+  std::vector<T> alphas() const { return coefficients().first; } // :118
+  std::vector<T> betas() const { return coefficients().second; } // :119
   /// Lanczos tridiagonal from the stored coefficients + QL implicit (:121-142), ascending.
-  std::vector<double> compute_eigenvalues() const
+  std::vector<T> compute_eigenvalues() const
   {
-    std::vector<double> e(4096);
+    std::vector<T> e(4096);
     const int n = pmg_cg_compute_eigenvalues(_s, e.data(), (int)e.size());
     if (n < 0)
       throw std::runtime_error(pmg_last_error()); // :125,138
     e.resize(n);
     return e;
   }
-  double residual() const
+  T residual() const // :144
   {
     double r = 0;
     check(pmg_cg_residual(_s, &r));
@@ -452,9 +586,9 @@ public:
   pmg_cg handle() const { return _s; }
 
 private:
-  std::pair<std::vector<double>, std::vector<double>> coefficients() const
+  std::pair<std::vector<T>, std::vector<T>> coefficients() const
   {
-    std::vector<double> a(4096), b(4096);
+    std::vector<T> a(4096), b(4096);
     const int n = pmg_cg_coefficients(_s, a.data(), b.data(), (int)a.size());
     if (n < 0)
       throw std::runtime_error(pmg_last_error());
@@ -465,15 +599,59 @@ private:
   std::shared_ptr<const IndexMap> _map;
   pmg_cg _s = nullptr;
 };
-} // namespace acc
-
-/// Interpolator<double> (src/interpolate.hpp:93-329).  The reference passes the two
-/// basix elements; on this path they are GLL tensor-product Lagrange elements, so
-/// the degrees say everything.  Dofmap spans are device memory (caller-owned),
-/// the cell lists host memory.
-class Interpolator
+/// The library's algebraic multigrid in the slot of the reference's CoarseSolverType<T>
+/// (src/amg.hpp:9-118: PETSc KSPCG + hypre BoomerAMG on the degree-1 level): `solve(x, y)` solves
+/// A x = y from a zero initial guess.  Constructed from the degree-1 operator.
+template <typename Vector>
+class AmgSolver
 {
 public:
+  template <typename Operator>
+  AmgSolver(Operator& coarse_operator, const std::shared_ptr<const IndexMap>& map)
+  {
+    check(pmg_amg_create(&_a, coarse_operator.handle(map), nullptr));
+  }
+  AmgSolver(const AmgSolver&) = delete;
+  AmgSolver& operator=(const AmgSolver&) = delete;
+  ~AmgSolver() { pmg_amg_destroy(_a); }
+  /// CG preconditioned by one AMG cycle (the default: 60 iterations, rtol 1e-5, src/amg.hpp:36-40).
+  void set_krylov(int max_iter, double rtol) { check(pmg_amg_set_krylov(_a, max_iter, rtol)); }
+  /// n AMG cycles from a zero initial guess: a fixed linear operator, no host synchronisation.
+  void set_cycles(int n) { check(pmg_amg_set_cycles(_a, n)); }
+  void set_smoother_iterations(int k) { check(pmg_amg_set_smoother_iterations(_a, k)); }
+  void solve(Vector& x, Vector& y) // src/amg.hpp:67-68
+  {
+    check(pmg_amg_solve(_a, x.mutable_array().data(), y.array().data(), &_its, nullptr));
+  }
+  int iterations() const { return _its; }
+  int num_levels() const { return pmg_amg_num_levels(_a); }
+  pmg_amg handle() const { return _a; }
+
+private:
+  pmg_amg _a = nullptr;
+  int _its = 0;
+};
+} // namespace acc
+
+/// Interpolator<T> (src/interpolate.hpp:93-329).  The reference passes the two basix
+/// elements (:104-107); on this path they are GLL tensor-product Lagrange elements, so
+/// their degree() says everything -- basix::FiniteElement<T> has that member,
+/// pmg_amd::LagrangeElement stands in for it without basix.  Dofmap spans are device memory
+/// (caller-owned), the cell lists host memory.
+template <typename T>
+class Interpolator
+{
+  static_assert(std::is_same_v<T, double>, "pmg_amd: the library computes in double");
+
+public:
+  template <typename Element>
+    requires requires(const Element& e) { e.degree(); }
+  Interpolator(const Element& Q1_element, const Element& Q2_element, std::span<const std::int32_t> Q1_dofmap,
+               std::span<const std::int32_t> Q2_dofmap, std::span<const std::int32_t> l_cells,
+               std::span<const std::int32_t> b_cells)
+      : Interpolator((int)Q1_element.degree(), (int)Q2_element.degree(), Q1_dofmap, Q2_dofmap, l_cells, b_cells)
+  {
+  }
   Interpolator(int degree_coarse, int degree_fine, std::span<const std::int32_t> dofmap_coarse,
                std::span<const std::int32_t> dofmap_fine, std::span<const std::int32_t> lcells,
                std::span<const std::int32_t> bcells)
@@ -491,16 +669,19 @@ public:
       pmg_interpolator_destroy(_ip);
   }
   /// Prolongation (:186-239).
-  void interpolate(acc::Vector& coarse, acc::Vector& fine)
+  template <typename Vector>
+  void interpolate(Vector& Q1_vector, Vector& Q2_vector)
   {
-    check(pmg_interpolator_interpolate(handle(coarse.map(), fine.map(), nullptr), coarse.mutable_array().data(),
-                                       fine.mutable_array().data(), nullptr));
+    check(pmg_interpolator_interpolate(handle(Q1_vector.map(), Q2_vector.map(), nullptr),
+                                       Q1_vector.mutable_array().data(), Q2_vector.mutable_array().data(), nullptr));
   }
   /// Restriction (:246-303).
-  void reverse_interpolate(acc::Vector& fine, acc::Vector& coarse)
+  template <typename Vector>
+  void reverse_interpolate(Vector& Q2_vector, Vector& Q1_vector)
   {
-    check(pmg_interpolator_reverse_interpolate(handle(coarse.map(), fine.map(), nullptr),
-                                               fine.mutable_array().data(), coarse.mutable_array().data(), nullptr));
+    check(pmg_interpolator_reverse_interpolate(handle(Q1_vector.map(), Q2_vector.map(), nullptr),
+                                               Q2_vector.mutable_array().data(), Q1_vector.mutable_array().data(),
+                                               nullptr));
   }
   /// Created on first use; if the fine-level operator is known by then (the V-cycle
   /// passes it) the transfers share its cell patches.
@@ -527,20 +708,25 @@ private:
 
 namespace acc
 {
-/// acc::MultigridPreconditioner (src/pmg.hpp:16-184).  Levels coarse -> fine.
-template <typename V = Vector, typename Operator = MatFreeLaplacian, typename Interp = pmg_amd::Interpolator,
-          typename Solver = Chebyshev<V>>
+/// acc::MultigridPreconditioner<Vector, Operator, Solver, CoarseSolver, Interpolator>
+/// (src/pmg.hpp:13-184), template parameters in the reference's order.  Levels coarse -> fine.
+/// CoarseSolver is any type with `solve(Vector& x, Vector& b)` (the reference's
+/// CoarseSolverType<T>, src/amg.hpp:67): it is reached through the C ABI's coarse-solver
+/// callback; the library's own solvers (CGSolver<Vector>, AmgSolver<Vector>) are wired natively.
+template <typename Vector, typename Operator, typename Solver, typename CoarseSolver, typename Interpolator>
 class MultigridPreconditioner
 {
+  using T = typename Vector::value_type;
+
 public:
   MultigridPreconditioner(std::vector<std::shared_ptr<const IndexMap>> maps, int /*bs*/,
-                          std::span<const std::int8_t> bc_marker_coarsest)
+                          std::span<const std::int8_t> bc_marker)
       : _maps(std::move(maps))
   {
     std::vector<pmg_layout> layouts;
     for (auto& m : _maps)
       layouts.push_back(m->layout());
-    check(pmg_multigrid_create(&_mg, (int)layouts.size(), layouts.data(), bc_marker_coarsest.data()));
+    check(pmg_multigrid_create(&_mg, (int)layouts.size(), layouts.data(), bc_marker.data()));
   }
   MultigridPreconditioner(const MultigridPreconditioner&) = delete;
   MultigridPreconditioner& operator=(const MultigridPreconditioner&) = delete;
@@ -551,28 +737,42 @@ public:
     _solvers = solvers;
     _wired = false;
   }
-  /// A CGSolver on the coarsest map (its iteration cap and tolerance apply; zero initial guess,
-  /// like the reference's KSP solve, src/amg.hpp:36-44) or nullptr for the smoother
-  /// (src/pmg.hpp:106-109).  The hypre BoomerAMG preconditioner of the reference's coarse
-  /// solver is third-party and out of scope: this CG is Jacobi-preconditioned.
-  void set_coarse_solver(std::shared_ptr<CGSolver<V>> solver) // :46
+  /// :46; nullptr = the level-0 smoother solves the coarsest level (:106-109).
+  void set_coarse_solver(std::shared_ptr<CoarseSolver> solver)
   {
-    _coarse = std::move(solver);
-    check(pmg_multigrid_set_coarse_solver(_mg, _coarse ? _coarse->handle() : nullptr));
+    _coarse_solver = std::move(solver);
+    if (!_coarse_solver)
+    {
+      check(pmg_multigrid_set_coarse_callback(_mg, nullptr, nullptr));
+      check(pmg_multigrid_set_coarse_solver(_mg, nullptr));
+      return;
+    }
+    if constexpr (requires(CoarseSolver& c) { { c.handle() } -> std::same_as<pmg_cg>; })
+      check(pmg_multigrid_set_coarse_solver(_mg, _coarse_solver->handle()));
+    else if constexpr (requires(CoarseSolver& c) { { c.handle() } -> std::same_as<pmg_amg>; })
+      check(pmg_multigrid_set_coarse_amg(_mg, _coarse_solver->handle()));
+    else
+    {
+      // any solve(Vector&, Vector&): the cycle hands over its coarsest-level arrays, the bridge
+      // moves them through two vectors on the coarsest map
+      _cx = std::make_unique<Vector>(_maps.front(), 1);
+      _cb = std::make_unique<Vector>(_maps.front(), 1);
+      check(pmg_multigrid_set_coarse_callback(_mg, &MultigridPreconditioner::coarse_bridge, this));
+    }
   }
   void set_operators(std::vector<std::shared_ptr<Operator>>& operators) // :48
   {
     _operators = operators;
     _wired = false;
   }
-  void set_interpolators(std::vector<std::shared_ptr<Interp>>& interpolators) // :50-53
+  void set_interpolators(std::vector<std::shared_ptr<Interpolator>>& interpolators) // :50-53
   {
-    _interpolators = interpolators;
+    _matfree_interpolation = interpolators;
     _wired = false;
   }
   /// x = rhs, y = initial guess in / result out (:56-155).  With verbose the final
   /// residual norm is computed and returned (the reference prints it, :147-150); else 0.
-  double apply(const V& x, V& y, bool verbose = false)
+  T apply(const Vector& x, Vector& y, bool verbose = false)
   {
     wire();
     double rnorm = 0;
@@ -586,12 +786,33 @@ public:
   }
 
 private:
+  static int coarse_bridge(void* user, double* x, double* b, pmg_stream stream)
+  {
+    auto* self = static_cast<MultigridPreconditioner*>(user);
+    try
+    {
+      const std::size_t n = self->_cx->array().size();
+      hipStream_t s = (hipStream_t)stream;
+      hip_check(hipMemcpyAsync(self->_cb->mutable_array().data(), b, sizeof(T) * n, hipMemcpyDeviceToDevice, s), "D2D");
+      hip_check(hipMemcpyAsync(self->_cx->mutable_array().data(), x, sizeof(T) * n, hipMemcpyDeviceToDevice, s), "D2D");
+      hip_check(hipStreamSynchronize(s), "sync"); // the caller's solver may work on any stream
+      self->_coarse_solver->solve(*self->_cx, *self->_cb);
+      hip_check(hipDeviceSynchronize(), "sync");
+      hip_check(hipMemcpyAsync(x, self->_cx->array().data(), sizeof(T) * n, hipMemcpyDeviceToDevice, s), "D2D");
+      return 0;
+    }
+    catch (const std::exception& e)
+    {
+      self->_coarse_error = e.what();
+      return 1;
+    }
+  }
   void wire()
   {
     if (_wired)
       return;
     const std::size_t L = _maps.size();
-    if (_operators.size() != L || _solvers.size() != L || _interpolators.size() + 1 != L)
+    if (_operators.size() != L || _solvers.size() != L || _matfree_interpolation.size() + 1 != L)
       throw std::runtime_error("MultigridPreconditioner: need one operator and solver per level and one "
                                "interpolator per pair of levels");
     std::vector<pmg_laplacian> ops;
@@ -603,7 +824,7 @@ private:
       sm.push_back(_solvers[i]->handle());
     }
     for (std::size_t i = 0; i + 1 < L; ++i)
-      ip.push_back(_interpolators[i]->handle(_maps[i], _maps[i + 1], ops[i + 1]));
+      ip.push_back(_matfree_interpolation[i]->handle(_maps[i], _maps[i + 1], ops[i + 1]));
     check(pmg_multigrid_set_operators(_mg, ops.data()));
     check(pmg_multigrid_set_solvers(_mg, sm.data()));
     check(pmg_multigrid_set_interpolators(_mg, ip.data()));
@@ -612,10 +833,29 @@ private:
   std::vector<std::shared_ptr<const IndexMap>> _maps;
   std::vector<std::shared_ptr<Operator>> _operators;
   std::vector<std::shared_ptr<Solver>> _solvers;
-  std::vector<std::shared_ptr<Interp>> _interpolators;
-  std::shared_ptr<CGSolver<V>> _coarse;
+  std::vector<std::shared_ptr<Interpolator>> _matfree_interpolation;
+  std::shared_ptr<CoarseSolver> _coarse_solver;
+  std::unique_ptr<Vector> _cx, _cb;
+  std::string _coarse_error;
   pmg_multigrid _mg = nullptr;
   bool _wired = false;
 };
 } // namespace acc
 } // namespace pmg_amd
+
+#ifdef PMG_AMD_DOLFINX_NAMESPACE
+// The reference's own namespaces, for translation units written against its headers
+// (`using namespace dolfinx;`, examples/pmg/main.cpp:29).
+namespace dolfinx
+{
+namespace common
+{
+using IndexMap = pmg_amd::IndexMap;
+}
+namespace acc
+{
+using namespace pmg_amd::acc;
+}
+} // namespace dolfinx
+using pmg_amd::Interpolator;
+#endif

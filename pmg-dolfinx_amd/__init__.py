@@ -5,6 +5,7 @@ Import as ``pmg_dolfinx_amd`` (the directory name carries a hyphen; the shim
 ``pmg_dolfinx_amd.py`` at the repository root loads it under that name).
 """
 from . import _lib  # noqa: F401
+from .amg import AmgSolver  # noqa: F401
 from .cg import CGSolver  # noqa: F401
 from .chebyshev import Chebyshev  # noqa: F401
 from .interpolate import Interpolator  # noqa: F401

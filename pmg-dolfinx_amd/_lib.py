@@ -117,12 +117,26 @@ _SIGS = {
     "pmg_multigrid_set_interpolators": (C.c_int, [vp, C.POINTER(vp)]),
     "pmg_multigrid_set_coarse_solver": (C.c_int, [vp, vp]),
     "pmg_multigrid_set_coarse_callback": (C.c_int, [vp, COARSE_FN, vp]),
+    "pmg_multigrid_set_coarse_amg": (C.c_int, [vp, vp]),
+    "pmg_amg_create": (C.c_int, [C.POINTER(vp), vp, vp]),
+    "pmg_amg_destroy": (C.c_int, [vp]),
+    "pmg_amg_set_smoother_iterations": (C.c_int, [vp, C.c_int]),
+    "pmg_amg_set_cycles": (C.c_int, [vp, C.c_int]),
+    "pmg_amg_set_krylov": (C.c_int, [vp, C.c_int, C.c_double]),
+    "pmg_amg_solve": (C.c_int, [vp, vp, vp, C.POINTER(C.c_int), vp]),
+    "pmg_amg_cycle": (C.c_int, [vp, vp, vp, vp]),
+    "pmg_amg_num_levels": (C.c_int, [vp]),
+    "pmg_amg_level_info": (C.c_int, [vp, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), c_dp]),
+    "pmg_amg_export": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                 C.POINTER(C.c_longlong), c_ip, c_ip, c_dp]),
+    "pmg_laplacian_set_geometry_batch": (C.c_int, [vp, C.c_longlong]),
+    "pmg_laplacian_geometry_bytes": (C.c_longlong, [vp]),
     "pmg_multigrid_apply": (C.c_int, [vp, vp, vp, c_dp, vp]),
     "pmg_multigrid_apply_counts": (C.c_int, [vp, C.POINTER(C.c_int), C.c_int]),
 }
 
 # functions whose int return value is a count, not a status
-_COUNT_FUNCS = {"pmg_comm_rank", "pmg_comm_size", "pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
+_COUNT_FUNCS = {"pmg_amg_num_levels", "pmg_laplacian_geometry_bytes", "pmg_comm_rank", "pmg_comm_size", "pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
                 "pmg_laplacian_degree", "pmg_laplacian_launches_per_apply", "pmg_laplacian_is_affine"}
 
 _lib = None

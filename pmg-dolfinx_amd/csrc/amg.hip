@@ -1,0 +1,887 @@
+// Algebraic multigrid for the coarsest (degree 1) level of the p-multigrid hierarchy.
+//
+// The reference solves its coarsest level with PETSc's KSPCG (at most 60 iterations) preconditioned
+// by hypre BoomerAMG on an assembled aijhipsparse matrix (src/amg.hpp:33-47, wired in at
+// src/pmg.hpp:106-107 through examples/pmg/main.cpp:331-335).  hypre and PETSc are third-party
+// arithmetic that is not part of this repository; this file is the library's own solver for that
+// slot, written for the same inputs the degree-1 operator already has:
+//
+//   set-up (host, once): the degree-1 stiffness matrix is assembled from the operator's geometry
+//     tensor (trilinear hexahedra with the 2-point GLL rule: a 7..27-point stencil); smoothed
+//     aggregation (Vanek, Mandel, Brezina 1996) builds the hierarchy: strength graph
+//     |a_ij| >= theta sqrt(a_ii a_jj), greedy aggregation, piecewise-constant tentative
+//     prolongator, one damped-Jacobi smoothing step P = (I - 4/(3 rho) D^-1 A) T, Galerkin
+//     product P^T A P; the last level is inverted densely.  Dirichlet rows (identity rows of the
+//     operator) stay out of the coarse spaces.
+//   cycle (device): V(k, k) with the same 4th-kind Chebyshev / Jacobi smoother as the p-levels
+//     (cheb_iterate), lean form (the pre-smoother leaves the residual, the post-smoother skips its
+//     last product), CSR products one sub-wavefront per row.  Nothing synchronises the host.
+//   solve: either a fixed number of cycles from a zero initial guess (a fixed linear operator: the
+//     p-multigrid cycle stays a valid CG preconditioner and can be captured in a graph), or the
+//     reference's shape -- CG on the matrix-free operator preconditioned by one cycle, to a
+//     relative tolerance, at most max_iter iterations.
+//
+// Several ranks: each rank's hierarchy is built on its owned-rows x owned-columns block (the ghost
+// couplings are dropped from the preconditioner, not from the operator), so the Krylov solve --
+// whose operator is the distributed matrix-free Laplacian -- converges to the global solution with
+// a block preconditioner.  A hierarchy that aggregates across ranks is the next step.
+//
+// Parity: unpinned by the reference (third-party arithmetic, no fixture).  The tests compare the
+// device cycle with a numpy restatement of the same hierarchy (oracle/amg_oracle.py) and check the
+// solver's defining properties (symmetry, contraction, h-independent iteration counts).
+#include "common.hpp"
+#include "patches.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <random>
+
+using namespace pmg;
+
+namespace pmg
+{
+int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s);
+pmg_layout laplacian_layout(pmg_laplacian op);
+PatchView laplacian_patches(pmg_laplacian op);
+struct LaplacianInputs
+{
+  int degree;
+  int32_t ncells;
+  const int32_t* dofmap; // device
+  const int8_t* bc;      // device
+  const double* kappa;   // device
+};
+LaplacianInputs laplacian_inputs(pmg_laplacian op);
+} // namespace pmg
+
+namespace
+{
+struct HostCsr
+{
+  int n = 0, m = 0; // rows, columns
+  std::vector<int> rp, ci;
+  std::vector<double> v;
+  long long nnz() const { return (long long)ci.size(); }
+};
+
+struct DevCsr
+{
+  int n = 0, m = 0, tpr = 4; // threads per row of the product kernels
+  int* rp = nullptr;
+  int* ci = nullptr;
+  double* v = nullptr;
+};
+
+template <typename T>
+int to_device(T** dst, const std::vector<T>& src)
+{
+  PMG_HIP(hipMalloc(dst, sizeof(T) * std::max<size_t>(src.size(), 1)));
+  if (!src.empty())
+    PMG_HIP(hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+  return PMG_OK;
+}
+
+int upload_csr(DevCsr& d, const HostCsr& h)
+{
+  d.n = h.n;
+  d.m = h.m;
+  const double avg = h.n ? (double)h.nnz() / h.n : 1.0;
+  d.tpr = avg > 48 ? 32 : avg > 24 ? 16 : avg > 10 ? 8 : avg > 4 ? 4 : 2;
+  PMG_TRY(to_device(&d.rp, h.rp));
+  PMG_TRY(to_device(&d.ci, h.ci));
+  PMG_TRY(to_device(&d.v, h.v));
+  return PMG_OK;
+}
+
+void free_csr(DevCsr& d)
+{
+  (void)hipFree(d.rp);
+  (void)hipFree(d.ci);
+  (void)hipFree(d.v);
+  d = DevCsr();
+}
+
+// ---- device products: TPR lanes of a wavefront share a row ------------------------------------
+// MODE 0: y = A x    1: y = b - A x    2: y += A x
+template <int TPR, int MODE>
+__global__ void csr_product_kernel(int n, const int* __restrict__ rp, const int* __restrict__ ci,
+                                   const double* __restrict__ v, const double* __restrict__ x,
+                                   const double* __restrict__ b, double* __restrict__ y)
+{
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = gid / TPR, sub = gid % TPR;
+  double acc = 0.0;
+  if (row < n)
+  {
+    const int e = rp[row + 1];
+    for (int k = rp[row] + sub; k < e; k += TPR)
+      acc += v[k] * x[ci[k]];
+  }
+#pragma unroll
+  for (int off = TPR / 2; off > 0; off >>= 1)
+    acc += __shfl_down(acc, off, TPR);
+  if (row < n && sub == 0)
+  {
+    if (MODE == 0)
+      y[row] = acc;
+    else if (MODE == 1)
+      y[row] = b[row] - acc;
+    else
+      y[row] += acc;
+  }
+}
+
+template <int MODE>
+int csr_product(const DevCsr& A, const double* x, const double* b, double* y, hipStream_t s)
+{
+  if (A.n == 0)
+    return PMG_OK;
+  const long long threads = (long long)A.n * A.tpr;
+  const int blocks = (int)((threads + 255) / 256);
+  switch (A.tpr)
+  {
+  case 2:
+    csr_product_kernel<2, MODE><<<blocks, 256, 0, s>>>(A.n, A.rp, A.ci, A.v, x, b, y);
+    break;
+  case 4:
+    csr_product_kernel<4, MODE><<<blocks, 256, 0, s>>>(A.n, A.rp, A.ci, A.v, x, b, y);
+    break;
+  case 8:
+    csr_product_kernel<8, MODE><<<blocks, 256, 0, s>>>(A.n, A.rp, A.ci, A.v, x, b, y);
+    break;
+  case 16:
+    csr_product_kernel<16, MODE><<<blocks, 256, 0, s>>>(A.n, A.rp, A.ci, A.v, x, b, y);
+    break;
+  default:
+    csr_product_kernel<32, MODE><<<blocks, 256, 0, s>>>(A.n, A.rp, A.ci, A.v, x, b, y);
+    break;
+  }
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+// y = Ainv b, dense n x n, one wavefront per row
+__global__ void dense_apply_kernel(int n, const double* __restrict__ Ainv, const double* __restrict__ b,
+                                   double* __restrict__ y)
+{
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= n)
+    return;
+  double acc = 0.0;
+  for (int k = lane; k < n; k += 64)
+    acc += Ainv[(size_t)row * n + k] * b[k];
+  for (int off = 32; off > 0; off >>= 1)
+    acc += __shfl_down(acc, off, 64);
+  if (lane == 0)
+    y[row] = acc;
+}
+
+// ---- host sparse algebra -------------------------------------------------------------------
+HostCsr transpose(const HostCsr& A)
+{
+  HostCsr T;
+  T.n = A.m;
+  T.m = A.n;
+  T.rp.assign(T.n + 1, 0);
+  for (int c : A.ci)
+    T.rp[c + 1]++;
+  for (int i = 0; i < T.n; ++i)
+    T.rp[i + 1] += T.rp[i];
+  T.ci.resize(A.ci.size());
+  T.v.resize(A.v.size());
+  std::vector<int> pos(T.rp.begin(), T.rp.end() - 1);
+  for (int i = 0; i < A.n; ++i)
+    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
+    {
+      const int p = pos[A.ci[k]]++;
+      T.ci[p] = i;
+      T.v[p] = A.v[k];
+    }
+  return T;
+}
+
+// C = A B (Gustavson), rows sorted by column
+HostCsr spgemm(const HostCsr& A, const HostCsr& B)
+{
+  HostCsr C;
+  C.n = A.n;
+  C.m = B.m;
+  C.rp.assign(C.n + 1, 0);
+  std::vector<int> marker(B.m, -1), cols;
+  std::vector<double> acc(B.m, 0.0);
+  for (int i = 0; i < A.n; ++i)
+  {
+    cols.clear();
+    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
+    {
+      const int j = A.ci[k];
+      const double a = A.v[k];
+      for (int l = B.rp[j]; l < B.rp[j + 1]; ++l)
+      {
+        const int c = B.ci[l];
+        if (marker[c] != i)
+        {
+          marker[c] = i;
+          acc[c] = 0.0;
+          cols.push_back(c);
+        }
+        acc[c] += a * B.v[l];
+      }
+    }
+    std::sort(cols.begin(), cols.end());
+    for (int c : cols)
+    {
+      C.ci.push_back(c);
+      C.v.push_back(acc[c]);
+    }
+    C.rp[i + 1] = (int)C.ci.size();
+  }
+  return C;
+}
+
+std::vector<double> diagonal(const HostCsr& A)
+{
+  std::vector<double> d(A.n, 0.0);
+  for (int i = 0; i < A.n; ++i)
+    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
+      if (A.ci[k] == i)
+        d[i] = A.v[k];
+  return d;
+}
+
+// largest eigenvalue of D^-1 A by the power method (A SPD: D^-1 A has real positive eigenvalues);
+// fixed seed and iteration count, so the hierarchy is reproducible
+double lambda_max_jacobi(const HostCsr& A, const std::vector<double>& d, int its)
+{
+  const int n = A.n;
+  if (n == 0)
+    return 1.0;
+  std::mt19937_64 gen(12345);
+  std::uniform_real_distribution<double> U(0.5, 1.0);
+  std::vector<double> x(n), y(n);
+  for (double& v : x)
+    v = U(gen);
+  double lam = 1.0;
+  for (int it = 0; it < its; ++it)
+  {
+    double nrm = 0;
+    for (int i = 0; i < n; ++i)
+    {
+      double s = 0;
+      for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
+        s += A.v[k] * x[A.ci[k]];
+      y[i] = s / d[i];
+      nrm += y[i] * y[i];
+    }
+    nrm = std::sqrt(nrm);
+    if (!(nrm > 0))
+      return 1.0;
+    double xn = 0;
+    for (int i = 0; i < n; ++i)
+      xn += x[i] * x[i];
+    lam = nrm / std::sqrt(xn);
+    for (int i = 0; i < n; ++i)
+      x[i] = y[i] / nrm;
+  }
+  return lam;
+}
+
+// Greedy aggregation on the strength graph.  agg[i] = aggregate of node i, -1 = the node takes no
+// part in the coarse space (no strong connection: Dirichlet rows, isolated nodes).
+int aggregate(const HostCsr& A, const std::vector<double>& d, double theta, std::vector<int>& agg)
+{
+  const int n = A.n;
+  std::vector<int> srp(n + 1, 0), sci;
+  std::vector<double> sw;
+  for (int i = 0; i < n; ++i)
+  {
+    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
+    {
+      const int j = A.ci[k];
+      if (j != i && std::fabs(A.v[k]) >= theta * std::sqrt(std::fabs(d[i] * d[j])) && A.v[k] != 0.0)
+      {
+        sci.push_back(j);
+        sw.push_back(std::fabs(A.v[k]));
+      }
+    }
+    srp[i + 1] = (int)sci.size();
+  }
+  agg.assign(n, -2); // -2 = undecided
+  int na = 0;
+  for (int i = 0; i < n; ++i)
+    if (srp[i] == srp[i + 1])
+      agg[i] = -1;
+  // pass 1: a node whose whole strong neighbourhood is free becomes a root
+  for (int i = 0; i < n; ++i)
+  {
+    if (agg[i] != -2)
+      continue;
+    bool free_nb = true;
+    for (int k = srp[i]; k < srp[i + 1] && free_nb; ++k)
+      free_nb = agg[sci[k]] == -2;
+    if (!free_nb)
+      continue;
+    agg[i] = na;
+    for (int k = srp[i]; k < srp[i + 1]; ++k)
+      agg[sci[k]] = na;
+    ++na;
+  }
+  // pass 2: leftovers join the aggregate (of pass 1) they are most strongly tied to
+  std::vector<int> agg1(agg);
+  for (int i = 0; i < n; ++i)
+  {
+    if (agg[i] != -2)
+      continue;
+    double best = 0;
+    int to = -2;
+    for (int k = srp[i]; k < srp[i + 1]; ++k)
+      if (agg1[sci[k]] >= 0 && sw[k] > best)
+      {
+        best = sw[k];
+        to = agg1[sci[k]];
+      }
+    if (to >= 0)
+      agg[i] = to;
+  }
+  // pass 3: what is still free forms aggregates of its own
+  for (int i = 0; i < n; ++i)
+  {
+    if (agg[i] != -2)
+      continue;
+    agg[i] = na;
+    for (int k = srp[i]; k < srp[i + 1]; ++k)
+      if (agg[sci[k]] == -2)
+        agg[sci[k]] = na;
+    ++na;
+  }
+  return na;
+}
+
+// P = (I - omega D^-1 A) T, T the normalised piecewise-constant tentative prolongator
+HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, const std::vector<int>& agg, int na,
+                             double omega)
+{
+  const int n = A.n;
+  std::vector<int> size(na, 0);
+  for (int i = 0; i < n; ++i)
+    if (agg[i] >= 0)
+      size[agg[i]]++;
+  std::vector<double> t(n, 0.0); // T[i, agg[i]]
+  for (int i = 0; i < n; ++i)
+    if (agg[i] >= 0)
+      t[i] = 1.0 / std::sqrt((double)size[agg[i]]);
+  HostCsr P;
+  P.n = n;
+  P.m = na;
+  P.rp.assign(n + 1, 0);
+  std::vector<int> marker(na, -1), cols;
+  std::vector<double> acc(na, 0.0);
+  for (int i = 0; i < n; ++i)
+  {
+    cols.clear();
+    auto add = [&](int c, double val) {
+      if (marker[c] != i)
+      {
+        marker[c] = i;
+        acc[c] = 0.0;
+        cols.push_back(c);
+      }
+      acc[c] += val;
+    };
+    if (agg[i] >= 0)
+    {
+      add(agg[i], t[i]);
+      for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
+      {
+        const int j = A.ci[k];
+        if (agg[j] >= 0)
+          add(agg[j], -omega * A.v[k] / d[i] * t[j]);
+      }
+    }
+    std::sort(cols.begin(), cols.end());
+    for (int c : cols)
+      if (acc[c] != 0.0)
+      {
+        P.ci.push_back(c);
+        P.v.push_back(acc[c]);
+      }
+    P.rp[i + 1] = (int)P.ci.size();
+  }
+  return P;
+}
+
+// dense inverse of an SPD matrix by Cholesky (n <= a few thousand); returns false if not SPD
+bool dense_spd_inverse(const HostCsr& A, std::vector<double>& inv)
+{
+  const int n = A.n;
+  std::vector<double> L((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i)
+    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
+      L[(size_t)i * n + A.ci[k]] = A.v[k];
+  for (int j = 0; j < n; ++j) // in-place lower Cholesky
+  {
+    double s = L[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k)
+      s -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+    if (!(s > 0.0))
+      return false;
+    const double ljj = std::sqrt(s);
+    L[(size_t)j * n + j] = ljj;
+    for (int i = j + 1; i < n; ++i)
+    {
+      double t = L[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k)
+        t -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+      L[(size_t)i * n + j] = t / ljj;
+    }
+  }
+  inv.assign((size_t)n * n, 0.0);
+  std::vector<double> col(n);
+  for (int c = 0; c < n; ++c) // solve L L^T x = e_c
+  {
+    for (int i = 0; i < n; ++i)
+    {
+      double t = (i == c) ? 1.0 : 0.0;
+      for (int k = 0; k < i; ++k)
+        t -= L[(size_t)i * n + k] * col[k];
+      col[i] = t / L[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i)
+    {
+      double t = col[i];
+      for (int k = i + 1; k < n; ++k)
+        t -= L[(size_t)k * n + i] * col[k];
+      col[i] = t / L[(size_t)i * n + i];
+    }
+    for (int i = 0; i < n; ++i)
+      inv[(size_t)i * n + c] = col[i];
+  }
+  return true;
+}
+} // namespace
+
+struct AmgLevel
+{
+  DevCsr A, P, R;
+  double* dinv = nullptr;
+  double lmax = 1.0;
+  int n = 0;
+  // work vectors of the level (x and b of level 0 are the caller's)
+  double *x = nullptr, *b = nullptr, *r = nullptr, *z = nullptr, *q = nullptr;
+  long long nnz = 0;
+};
+
+struct pmg_amg_s
+{
+  pmg_laplacian op = nullptr; // the degree-1 operator (Krylov mode applies it)
+  pmg_layout layout = nullptr;
+  std::vector<AmgLevel> levels;
+  double* dense_inv = nullptr; // coarsest level, n x n
+  int n_coarsest = 0;
+  int smoother_its = 2;
+  int cycles = 0;       // > 0: stationary mode, that many cycles per solve
+  int max_iter = 60;    // Krylov mode (src/amg.hpp:39-40)
+  double rtol = 1e-5;   // KSP's default relative tolerance
+  pmg_cg cg = nullptr;  // work vectors of the Krylov mode
+  double* xc = nullptr; // stationary mode with several cycles: correction
+  int last_iterations = 0;
+  // host copy of the hierarchy for pmg_amg_export (tests)
+  std::vector<HostCsr> hA, hP;
+  std::vector<double> hlmax;
+};
+
+namespace
+{
+int alloc_d(double** p, size_t n)
+{
+  PMG_HIP(hipMalloc(p, sizeof(double) * std::max<size_t>(n, 1)));
+  PMG_HIP(hipMemset(*p, 0, sizeof(double) * std::max<size_t>(n, 1)));
+  return PMG_OK;
+}
+
+// One V(k, k) cycle on level l: x = cycle(b), from a zero initial guess.
+int amg_cycle(pmg_amg amg, int l, double* x, const double* b, hipStream_t s)
+{
+  const int L = (int)amg->levels.size();
+  AmgLevel& lv = amg->levels[l];
+  if (l == L - 1)
+  {
+    if (amg->dense_inv)
+    {
+      if (lv.n > 0)
+        dense_apply_kernel<<<(lv.n * 64 + 255) / 256, 256, 0, s>>>(lv.n, amg->dense_inv, b, x);
+      PMG_HIP(hipGetLastError());
+      return PMG_OK;
+    }
+    // a coarsest level too large to invert: smooth it harder
+    const ChebWork w{lv.r, lv.z, lv.q};
+    return cheb_iterate(
+        w, [&lv, s](double* in, double* out) { return csr_product<0>(lv.A, in, nullptr, out, s); }, lv.dinv, lv.n,
+        lv.lmax, 4 * amg->smoother_its, x, b, false, true, s);
+  }
+  const ChebWork w{lv.r, lv.z, lv.q};
+  const ApplyFn A = [&lv, s](double* in, double* out) { return csr_product<0>(lv.A, in, nullptr, out, s); };
+  AmgLevel& lc = amg->levels[l + 1];
+  PMG_TRY(cheb_iterate(w, A, lv.dinv, lv.n, lv.lmax, amg->smoother_its, x, b, true, true, s)); // leaves r = b - A x
+  PMG_TRY(csr_product<0>(lv.R, lv.r, nullptr, lc.b, s));
+  PMG_TRY(amg_cycle(amg, l + 1, lc.x, lc.b, s));
+  PMG_TRY(csr_product<2>(lv.P, lc.x, nullptr, x, s)); // x += P x_c
+  PMG_TRY(cheb_iterate(w, A, lv.dinv, lv.n, lv.lmax, amg->smoother_its, x, b, false, false, s));
+  return PMG_OK;
+}
+} // namespace
+
+namespace pmg
+{
+pmg_layout amg_layout(pmg_amg amg) { return amg->layout; }
+
+// x = (approximately) A^-1 b on the coarsest p-level, x zero on entry is not assumed
+int amg_solve(pmg_amg amg, double* x, const double* b, hipStream_t s)
+{
+  Range range("pmg:amg_solve");
+  pmg_layout l = amg->layout;
+  const int n = l->size_local;
+  if (amg->cycles > 0)
+  {
+    PMG_REQUIRE(!l->multi_rank(), "pmg_amg: the stationary mode is a single-rank solver (the hierarchy is built "
+                                  "on the rank's own block); use the Krylov mode on several ranks");
+    PMG_TRY(amg_cycle(amg, 0, x, b, s));
+    AmgLevel& l0 = amg->levels[0];
+    for (int c = 1; c < amg->cycles; ++c) // x += cycle(b - A x)
+    {
+      PMG_TRY(csr_product<1>(l0.A, x, b, l0.b, s));
+      PMG_TRY(amg_cycle(amg, 0, amg->xc, l0.b, s));
+      launch_add(n, x, amg->xc, s);
+    }
+    amg->last_iterations = amg->cycles;
+    return PMG_OK;
+  }
+  // the reference's shape: CG (<= max_iter, rtol) on the operator, preconditioned by one cycle
+  PMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * l->total(), s)); // KSP-style zero initial guess
+  pmg_laplacian op = amg->op;
+  const ApplyFn A = [op, s](double* in, double* out) { return laplacian_apply(op, in, out, s); };
+  const PrecondFn M = [amg, s](double* z, const double* r) { return amg_cycle(amg, 0, z, r, s); };
+  PMG_TRY(pmg_cg_set_max_iterations(amg->cg, amg->max_iter));
+  PMG_TRY(pmg_cg_set_tolerance(amg->cg, amg->rtol));
+  return cg_iterate(amg->cg, A, nullptr, &M, false, x, b, &amg->last_iterations, s);
+}
+} // namespace pmg
+
+extern "C" int pmg_amg_create(pmg_amg* out, pmg_laplacian op, pmg_stream stream)
+{
+  PMG_REQUIRE(out && op, "pmg_amg_create: NULL argument");
+  const LaplacianInputs in = laplacian_inputs(op);
+  PMG_REQUIRE(in.degree == 1, "pmg_amg_create: the operator must have degree 1 (it has degree %d)", in.degree);
+  hipStream_t s = S(stream);
+  pmg_layout layout = laplacian_layout(op);
+  const int n = layout->size_local, total = layout->total();
+  auto* amg = new pmg_amg_s;
+  HandleGuard<pmg_amg> guard(amg, pmg_amg_destroy);
+  amg->op = op;
+  amg->layout = layout;
+
+  // ---- level 0: assemble the owned block of the degree-1 stiffness matrix ----
+  std::vector<int32_t> dofmap((size_t)in.ncells * 8);
+  std::vector<int8_t> bc(total);
+  std::vector<double> kappa(in.ncells), G((size_t)in.ncells * 8 * 6);
+  {
+    double* dG = nullptr;
+    PMG_HIP(hipMalloc(&dG, sizeof(double) * std::max<size_t>(G.size(), 1)));
+    int rc = pmg_laplacian_get_geometry(op, dG, stream);
+    if (rc == PMG_OK && !G.empty())
+      rc = hipMemcpyAsync(G.data(), dG, sizeof(double) * G.size(), hipMemcpyDeviceToHost, s) == hipSuccess
+               ? PMG_OK
+               : fail(PMG_ERR_HIP, "pmg_amg_create: copy of the geometry tensor failed");
+    if (rc == PMG_OK)
+      rc = hipStreamSynchronize(s) == hipSuccess ? PMG_OK : fail(PMG_ERR_HIP, "pmg_amg_create: synchronise failed");
+    (void)hipFree(dG);
+    PMG_TRY(rc);
+  }
+  if (in.ncells > 0)
+  {
+    PMG_HIP(hipMemcpy(dofmap.data(), in.dofmap, sizeof(int32_t) * dofmap.size(), hipMemcpyDeviceToHost));
+    PMG_HIP(hipMemcpy(kappa.data(), in.kappa, sizeof(double) * kappa.size(), hipMemcpyDeviceToHost));
+  }
+  if (total > 0)
+    PMG_HIP(hipMemcpy(bc.data(), in.bc, sizeof(int8_t) * bc.size(), hipMemcpyDeviceToHost));
+
+  // the cells the operator lists (both cell lists), from its patches
+  const PatchView pv = laplacian_patches(op);
+  std::vector<int32_t> cells;
+  for (int32_t c : *pv.pcell_h)
+    if (c >= 0)
+      cells.push_back(c);
+
+  HostCsr A0;
+  {
+    constexpr int W = 32; // row capacity of the fast path (a trilinear hex mesh has <= 27)
+    std::vector<int> cnt(n, 0), cols((size_t)n * W, -1);
+    std::vector<double> vals((size_t)n * W, 0.0);
+    std::vector<std::vector<std::pair<int, double>>> spill(0);
+    std::vector<int> spill_of(n, -1);
+    auto add = [&](int row, int col, double v) {
+      int* rc = cols.data() + (size_t)row * W;
+      double* rv = vals.data() + (size_t)row * W;
+      const int c = cnt[row];
+      for (int k = 0; k < c && k < W; ++k)
+        if (rc[k] == col)
+        {
+          rv[k] += v;
+          return;
+        }
+      if (c < W)
+      {
+        rc[c] = col;
+        rv[c] = v;
+        cnt[row] = c + 1;
+        return;
+      }
+      if (spill_of[row] < 0)
+      {
+        spill_of[row] = (int)spill.size();
+        spill.emplace_back();
+      }
+      auto& sp = spill[spill_of[row]];
+      for (auto& e : sp)
+        if (e.first == col)
+        {
+          e.second += v;
+          return;
+        }
+      sp.emplace_back(col, v);
+    };
+    for (int32_t c : cells)
+    {
+      const int32_t* dm = dofmap.data() + (size_t)c * 8;
+      const double* Gc = G.data() + (size_t)c * 48;
+      double Ke[8][8] = {};
+      // collocated basis on the 2-point GLL rule: at quadrature point q only the basis functions of
+      // q itself and of its three axis neighbours have a gradient; l_0' = -1, l_1' = +1
+      for (int q = 0; q < 8; ++q)
+      {
+        const double* g = Gc + q * 6; // (G00, G01, G02, G11, G12, G22), src/laplacian.hpp:99-111
+        const double Gm[3][3] = {{g[0], g[1], g[2]}, {g[1], g[3], g[4]}, {g[2], g[4], g[5]}};
+        const int qa = (q >> 2) & 1, qb = (q >> 1) & 1, qc = q & 1;
+        const int node[4] = {q, q ^ 4, q ^ 2, q ^ 1};
+        const double sa = qa ? 1.0 : -1.0, sb = qb ? 1.0 : -1.0, sc = qc ? 1.0 : -1.0;
+        const double grad[4][3] = {{sa, sb, sc}, {-sa, 0, 0}, {0, -sb, 0}, {0, 0, -sc}};
+        for (int i = 0; i < 4; ++i)
+          for (int j = 0; j < 4; ++j)
+          {
+            double v = 0;
+            for (int d = 0; d < 3; ++d)
+              for (int e = 0; e < 3; ++e)
+                v += grad[i][d] * Gm[d][e] * grad[j][e];
+            Ke[node[i]][node[j]] += kappa[c] * v;
+          }
+      }
+      for (int i = 0; i < 8; ++i)
+      {
+        const int row = dm[i];
+        if (row >= n || bc[row])
+          continue; // ghost rows are another rank's; Dirichlet rows are identity rows
+        for (int j = 0; j < 8; ++j)
+        {
+          const int col = dm[j];
+          if (col >= n || bc[col])
+            continue; // ghost columns: dropped from the preconditioner; Dirichlet columns: masked
+          add(row, col, Ke[i][j]);
+        }
+      }
+    }
+    A0.n = A0.m = n;
+    A0.rp.assign(n + 1, 0);
+    std::vector<std::pair<int, double>> row;
+    for (int i = 0; i < n; ++i)
+    {
+      row.clear();
+      for (int k = 0; k < std::min(cnt[i], W); ++k)
+        row.emplace_back(cols[(size_t)i * W + k], vals[(size_t)i * W + k]);
+      if (spill_of[i] >= 0)
+        row.insert(row.end(), spill[spill_of[i]].begin(), spill[spill_of[i]].end());
+      if (row.empty())
+        row.emplace_back(i, 1.0); // Dirichlet dof, or a dof of no listed cell: identity row
+      std::sort(row.begin(), row.end());
+      for (auto& e : row)
+      {
+        A0.ci.push_back(e.first);
+        A0.v.push_back(e.second);
+      }
+      A0.rp[i + 1] = (int)A0.ci.size();
+    }
+  }
+
+  // ---- the hierarchy ----
+  const int max_levels = 12, coarsest_max = 800;
+  std::vector<HostCsr> As, Ps;
+  As.push_back(std::move(A0));
+  std::vector<double> lmaxs;
+  double theta = 0.08;
+  while (true)
+  {
+    const HostCsr& A = As.back();
+    const std::vector<double> d = diagonal(A);
+    for (int i = 0; i < A.n; ++i)
+      PMG_REQUIRE(d[i] > 0.0, "pmg_amg_create: non-positive diagonal entry on level %d", (int)As.size() - 1);
+    const double rho = 1.05 * lambda_max_jacobi(A, d, 20);
+    lmaxs.push_back(rho);
+    if (A.n <= coarsest_max || (int)As.size() >= max_levels)
+      break;
+    std::vector<int> agg;
+    const int na = aggregate(A, d, theta, agg);
+    if (na == 0 || na >= A.n)
+      break; // nothing to coarsen
+    HostCsr P = smoothed_prolongator(A, d, agg, na, 4.0 / (3.0 * rho));
+    HostCsr R = transpose(P);
+    HostCsr AP = spgemm(A, P);
+    HostCsr Ac = spgemm(R, AP);
+    Ps.push_back(std::move(P));
+    As.push_back(std::move(Ac));
+    theta *= 0.5;
+  }
+
+  const int L = (int)As.size();
+  amg->levels.resize(L);
+  for (int l = 0; l < L; ++l)
+  {
+    AmgLevel& lv = amg->levels[l];
+    lv.n = As[l].n;
+    lv.nnz = As[l].nnz();
+    lv.lmax = lmaxs[l];
+    PMG_TRY(upload_csr(lv.A, As[l]));
+    std::vector<double> dinv = diagonal(As[l]);
+    for (double& v : dinv)
+      v = 1.0 / v;
+    PMG_TRY(to_device(&lv.dinv, dinv));
+    if (l + 1 < L)
+    {
+      PMG_TRY(upload_csr(lv.P, Ps[l]));
+      PMG_TRY(upload_csr(lv.R, transpose(Ps[l])));
+    }
+    const size_t len = (l == 0) ? (size_t)total : (size_t)lv.n;
+    PMG_TRY(alloc_d(&lv.r, len));
+    PMG_TRY(alloc_d(&lv.z, len));
+    PMG_TRY(alloc_d(&lv.q, len));
+    PMG_TRY(alloc_d(&lv.b, len)); // level 0: the residual of the second and later stationary cycles
+    if (l > 0)
+      PMG_TRY(alloc_d(&lv.x, len));
+  }
+  PMG_TRY(alloc_d(&amg->xc, (size_t)total));
+  // coarsest level: dense inverse when small enough
+  {
+    const HostCsr& Ac = As.back();
+    std::vector<double> inv;
+    if (Ac.n <= 4096 && dense_spd_inverse(Ac, inv))
+    {
+      amg->n_coarsest = Ac.n;
+      PMG_TRY(to_device(&amg->dense_inv, inv));
+    }
+  }
+  PMG_TRY(pmg_cg_create(&amg->cg, layout));
+  amg->hA = std::move(As);
+  amg->hP = std::move(Ps);
+  amg->hlmax = lmaxs;
+  PMG_HIP(hipStreamSynchronize(s));
+  *out = guard.release();
+  return PMG_OK;
+}
+
+extern "C" int pmg_amg_destroy(pmg_amg amg)
+{
+  if (!amg)
+    return PMG_OK;
+  for (AmgLevel& lv : amg->levels)
+  {
+    free_csr(lv.A);
+    free_csr(lv.P);
+    free_csr(lv.R);
+    (void)hipFree(lv.dinv);
+    (void)hipFree(lv.x);
+    (void)hipFree(lv.b);
+    (void)hipFree(lv.r);
+    (void)hipFree(lv.z);
+    (void)hipFree(lv.q);
+  }
+  (void)hipFree(amg->dense_inv);
+  (void)hipFree(amg->xc);
+  pmg_cg_destroy(amg->cg);
+  delete amg;
+  return PMG_OK;
+}
+
+extern "C" int pmg_amg_set_smoother_iterations(pmg_amg amg, int k)
+{
+  PMG_REQUIRE(amg && k >= 1, "pmg_amg_set_smoother_iterations: bad argument");
+  amg->smoother_its = k;
+  return PMG_OK;
+}
+
+extern "C" int pmg_amg_set_cycles(pmg_amg amg, int cycles)
+{
+  PMG_REQUIRE(amg && cycles >= 0, "pmg_amg_set_cycles: bad argument");
+  amg->cycles = cycles;
+  return PMG_OK;
+}
+
+extern "C" int pmg_amg_set_krylov(pmg_amg amg, int max_iter, double rtol)
+{
+  PMG_REQUIRE(amg && max_iter >= 0 && rtol >= 0.0, "pmg_amg_set_krylov: bad argument");
+  amg->max_iter = max_iter;
+  amg->rtol = rtol;
+  amg->cycles = 0;
+  return PMG_OK;
+}
+
+extern "C" int pmg_amg_solve(pmg_amg amg, double* x, const double* b, int* iterations, pmg_stream stream)
+{
+  PMG_REQUIRE(amg && x && b, "pmg_amg_solve: NULL argument");
+  PMG_REQUIRE(x != b, "pmg_amg_solve: x and b alias");
+  PMG_TRY(amg_solve(amg, x, b, S(stream)));
+  if (iterations)
+    *iterations = amg->last_iterations;
+  return PMG_OK;
+}
+
+extern "C" int pmg_amg_cycle(pmg_amg amg, double* x, const double* b, pmg_stream stream)
+{
+  PMG_REQUIRE(amg && x && b && x != b, "pmg_amg_cycle: bad argument");
+  return amg_cycle(amg, 0, x, b, S(stream));
+}
+
+extern "C" int pmg_amg_num_levels(pmg_amg amg) { return amg ? (int)amg->levels.size() : -1; }
+
+extern "C" int pmg_amg_level_info(pmg_amg amg, int level, long long* rows, long long* nnz, double* lambda_max)
+{
+  PMG_REQUIRE(amg && level >= 0 && level < (int)amg->levels.size(), "pmg_amg_level_info: bad level");
+  if (rows)
+    *rows = amg->levels[level].n;
+  if (nnz)
+    *nnz = amg->levels[level].nnz;
+  if (lambda_max)
+    *lambda_max = amg->levels[level].lmax;
+  return PMG_OK;
+}
+
+// which = 0: A_level, 1: P_level (level -> level + 1).  Call with NULL arrays for the sizes.
+extern "C" int pmg_amg_export(pmg_amg amg, int level, int which, long long* rows, long long* cols, long long* nnz,
+                              int32_t* rowptr, int32_t* colidx, double* values)
+{
+  PMG_REQUIRE(amg && level >= 0 && (which == 0 || which == 1), "pmg_amg_export: bad argument");
+  const std::vector<HostCsr>& src = which == 0 ? amg->hA : amg->hP;
+  PMG_REQUIRE(level < (int)src.size(), "pmg_amg_export: no such level");
+  const HostCsr& M = src[level];
+  if (rows)
+    *rows = M.n;
+  if (cols)
+    *cols = M.m;
+  if (nnz)
+    *nnz = M.nnz();
+  if (rowptr)
+    std::copy(M.rp.begin(), M.rp.end(), rowptr);
+  if (colidx)
+    std::copy(M.ci.begin(), M.ci.end(), colidx);
+  if (values)
+    std::copy(M.v.begin(), M.v.end(), values);
+  return PMG_OK;
+}

@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -127,6 +128,20 @@ struct Range
   Range& operator=(const Range&) = delete;
   ~Range() { range_pop(); }
 };
+
+// solvers.hip -- the 4th-kind Chebyshev / Jacobi smoother (src/chebyshev.hpp:46-91) and the CG loop
+// (src/cg.hpp:147-222) over ANY operator and preconditioner given as callables (the matrix-free
+// Laplacian, an assembled CSR level of the AMG hierarchy; the diagonal, a V-cycle, an AMG cycle)
+struct ChebWork
+{
+  double *r = nullptr, *z = nullptr, *q = nullptr;
+};
+using ApplyFn = std::function<int(double* in, double* out)>;
+using PrecondFn = std::function<int(double* z, const double* r)>;
+int cg_iterate(pmg_cg cg, const ApplyFn& A, const double* dinv, const PrecondFn* M, bool flexible, double* x,
+               const double* b, int* iterations, hipStream_t s);
+int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n, double lmax, int max_iter,
+                 double* x, const double* b, bool need_r, bool x_zero, hipStream_t s);
 
 // vector.hip -- stream-ordered building blocks used by the solvers
 // local dot of the owned entries into the result slot `slot` of the layout (device)

@@ -174,14 +174,14 @@ __device__ __forceinline__ void tbarrier()
 {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-__device__ __forceinline__ int ftab(int column, int ndf, int a, int b, int c)
+__device__ __forceinline__ int ftab(int ndf, int a, int b, int c) // layer-major tables, patches.hpp
 {
-  return column ? c * ndf * ndf + a * ndf + b : (a * ndf + b) * ndf + c;
+  return c * ndf * ndf + a * ndf + b;
 }
 
 struct TransferArgs
 {
-  int first, ndc, ndf, column, K, max_mf, max_mc;
+  int first, ndc, ndf, K, max_mf, max_mc;
   int nt; // stream the fine vector (nt loads): its level does not fit the MALL anyway
   const int32_t *poff, *lmap_id, *pncell, *cpoff, *clmap_id;
   const uint32_t *pdofs, *cpdofs;
@@ -232,7 +232,7 @@ __global__ void prolong_patch_kernel(TransferArgs A, const double* __restrict__ 
     {
       const int o = lane + 64 * j, oc = o < Nf ? o : Nf - 1;
       const int a = oc / (ndf * ndf), r = oc - a * ndf * ndf, b = r / ndf, c = r - b * ndf;
-      fi[j] = fl[(size_t)slot * Nf + ftab(A.column, ndf, a, b, c)];
+      fi[j] = fl[(size_t)slot * Nf + ftab(ndf, a, b, c)];
     }
   };
   if (wave < nc)
@@ -384,7 +384,7 @@ __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__
     {
       const int o = lane + 64 * j, oc = o < Nf ? o : Nf - 1;
       const int a = oc / (ndf * ndf), r = oc - a * ndf * ndf, b = r / ndf, c = r - b * ndf;
-      fi[j] = fl[(size_t)slot * Nf + ftab(A.column, ndf, a, b, c)];
+      fi[j] = fl[(size_t)slot * Nf + ftab(ndf, a, b, c)];
     }
   };
   if (wave < nc)
@@ -534,7 +534,6 @@ TransferArgs make_args(pmg_interpolator ip, int first)
   A.first = first;
   A.ndc = ip->ndc;
   A.ndf = ip->ndf;
-  A.column = ip->fv.column ? 1 : 0;
   A.K = ip->fv.K;
   A.max_mf = ip->fv.max_m;
   A.max_mc = ip->cmax_m;

@@ -3,35 +3,39 @@
 // Replaces src/laplacian.hpp (geometry_computation :22-113, stiffness_operator
 // :143-278, MatFreeLaplacian :284-526) of the reference.
 //
-// Work decomposition: cells are grouped into coloured patches (patches.hpp); one
-// workgroup applies the operator to one patch (2x2x2 cells = 1000 threads at
-// P = 4), one thread per (cell, dof).
+// Work decomposition: cells are grouped into coloured patches (patches.hpp: 2x2x8
+// cells at P = 4); one workgroup of up to 8 wavefronts applies the operator to one
+// patch.  A wavefront takes whole cells (2 at P = 4; at P = 8 two wavefronts share
+// one), a lane owns the column of nd points above (a, b), keeps it in registers and
+// marches through the nd layers (stiffness_column_kernel below).
 //
 // HBM layout (owned by the handle):
-//   G      [slot][3][N] double2 : (G00,G01) (G02,G11) (G12,G22) per quadrature
-//          point, slot = patch * K + position in the patch, so a wave reads 1 KiB
-//          contiguous per load instruction (the reference stores [cell][q][6] AoS,
-//          48-byte stride per lane, src/laplacian.hpp:221-227).
+//   G      [slot][layer c][3][nd*nd] double2 : (G00,G01) (G02,G11) (G12,G22) per
+//          quadrature point, slot = patch * K + position in the patch, so one layer
+//          of one cell is 3 contiguous runs of nd*nd double2 (the reference stores
+//          [cell][q][6] AoS, 48-byte stride per lane, src/laplacian.hpp:221-227);
+//          P = 2 uses the line-aligned flat variant described at gflat() below.
 //   pdofs  [poff[p] .. poff[p+1]) uint32 : sorted dofs of patch p, Dirichlet and
 //          "already written" flags in the top bits -- replaces the per-thread
 //          dofmap load + dependent 1-byte bc_marker gather (:182-189) and the
 //          zero-fill of y (:466).
-//   lmaps  [table][K*N] uint16 : position of (cell slot, local dof) in the patch
-//          list; identical patches share one table (a structured box has one
+//   lmaps  [table][K*N] uint16 : position of (cell slot, layer-major local dof) in the
+//          patch list; identical patches share one table (a structured box has one
 //          table for all interior patches, so it stays in L2).
-//   D      [nd][nd] double : 1-D derivative table, staged in LDS per workgroup.
+//   D      [nd][nd] double : 1-D derivative table (LDS -> registers / SGPRs).
 //
-// LDS per workgroup: patch x values, patch y accumulators, element dofs and the
-// three flux components (6 * K*N doubles, 48 KB at P = 4).  The 1-D contractions
-// read LDS conflict-free (the strided index is uniform across most of a wave, so
-// reads broadcast).  Cell contributions are summed with LDS FP64 atomics
-// (ds_add_f64), the global write is a plain store / read-modify-write.
+// LDS per workgroup: patch x values and patch y accumulators (2 * max_m doubles, 43 KB
+// at P = 4) plus three nd x nd slices per cell in flight.  Cell contributions are summed
+// with LDS FP64 atomics (ds_add_f64), the global write is a plain store /
+// read-modify-write (coloured launches) or one global atomic per patch dof (merged
+// launches of small levels and of the boundary shell).
 //
 // Roofline: HBM-bound, AI 0.85 (P=1) .. 2.05 (P=8) flop/B; algorithmic bytes per
 // cell 48N + 4N + 8 + 17U (model "storedG").
 #include "common.hpp"
 #include "patches.hpp"
 
+#include <algorithm>
 #include <cmath>
 
 using namespace pmg;
@@ -77,6 +81,9 @@ struct pmg_laplacian_s
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   long long launches = 0; // full operator applications' kernel launches since creation
   long long applies = 0;
+  // geometry batching (src/laplacian.hpp:383-396): > 0 = G is not resident; it is recomputed for
+  // `batch_patches` patches at a time into a buffer of that size, in every application
+  int32_t batch_patches = 0;
   // in-situ timing of the stiffness launches (pmg_laplacian_set_profiling)
   bool profiling = false;
   std::vector<hipEvent_t> prof_events; // pairs: before / after a run of launches
@@ -93,13 +100,8 @@ struct Shape
   static constexpr int N = ND * ND * ND;
   static constexpr PatchShape PS = patch_shape(P);
   static constexpr int K = PS.bx * PS.by * PS.bz; // cells per patch
-  static constexpr int CPR = PS.cpr;              // cells per round
-  static constexpr int ROUNDS = K / CPR;
   static constexpr int MAXM = PS.max_m;           // patch dofs held in LDS
-  static constexpr int RN = CPR * N;              // (cell, dof) pairs per round
-  static constexpr int THREADS = ((RN + 63) / 64) * 64;
-  static constexpr int ITER = (MAXM + THREADS - 1) / THREADS; // gather / store passes
-  // column kernel: a wave takes CW whole cells, a lane one (a, b) column
+  // a wave takes CW whole cells, a lane one (a, b) column
   static constexpr int NQ2 = ND * ND;
   static constexpr int CW = NQ2 <= 64 ? 64 / NQ2 : 1;
   static constexpr int WPC = (NQ2 + 63) / 64;      // waves that share one cell (2 at P = 8)
@@ -115,7 +117,6 @@ struct Shape
   static constexpr int NW = NG * WPC;                                  // waves per workgroup
   static constexpr int WTHREADS = NW * 64;
   static constexpr int WITER = (MAXM + WTHREADS - 1) / WTHREADS;
-  static_assert(K % CPR == 0, "rounds must tile the patch");
   static_assert(MAXM <= 65535, "patch positions are 16-bit");
 };
 
@@ -156,9 +157,8 @@ __device__ inline void jacobian(const double* __restrict__ xgeom,
 }
 
 // Layout of the stored geometry tensor G (double2 pairs (G00,G01)(G02,G11)(G12,G22)).
-//   block kernel : [slot][pair][q]
-//   column kernel: [slot][layer c][pair][a*nd+b]
-//   flat (column kernel, degrees in PMG_GFLAT_MASK): [patch][item][layer c][pair][cell of the item][a*nd+b],
+//   default: [slot][layer c][pair][a*nd+b]
+//   flat (degrees in PMG_GFLAT_MASK): [patch][item][layer c][pair][cell of the item][a*nd+b],
 //     every (item, layer) block padded to whole 128-byte lines -- a wavefront then reads its item's
 //     layer as NJ full-width loads of 64 consecutive double2 (whole lines, none shared between two
 //     load instructions) and hands the values to the lanes that use them through LDS.  Pays where
@@ -171,27 +171,25 @@ __device__ inline void jacobian(const double* __restrict__ xgeom,
 __host__ __device__ constexpr bool gflat(int nd) { return nd * nd <= 64 && ((PMG_GFLAT_MASK >> (nd - 1)) & 1); }
 __host__ __device__ constexpr int gcw(int nd) { return nd * nd <= 64 ? 64 / (nd * nd) : 1; }
 __host__ __device__ constexpr int gls(int nd) { return ((3 * gcw(nd) * nd * nd + 7) / 8) * 8; } // layer stride
-__host__ __device__ constexpr long long gpatch(int column, int nd, int K)
+__host__ __device__ constexpr long long gpatch(int nd, int K)
 {
-  return (column && gflat(nd)) ? (long long)((K + gcw(nd) - 1) / gcw(nd)) * nd * gls(nd)
-                               : (long long)K * 3 * nd * nd * nd;
+  return gflat(nd) ? (long long)((K + gcw(nd) - 1) / gcw(nd)) * nd * gls(nd) : (long long)K * 3 * nd * nd * nd;
 }
 // absolute position of (patch slot, quadrature point q = (a,b,c), component pair)
-__device__ __forceinline__ size_t gpos(int column, int nd, int K, long long slot, int q, int pair)
+__device__ __forceinline__ size_t gpos(int nd, int K, long long slot, int q, int pair)
 {
   const int nsq = nd * nd, N = nsq * nd;
-  if (!column)
-    return (size_t)slot * 3 * N + pair * N + q;
   const int a = q / nsq, b = (q - a * nsq) / nd, c = q - a * nsq - b * nd;
   if (!gflat(nd))
     return (size_t)slot * 3 * N + (c * 3 + pair) * nsq + a * nd + b;
   const long long p = slot / K;
   const int sl = (int)(slot - p * K), cw = gcw(nd), item = sl / cw, ci = sl - item * cw;
-  return (size_t)p * gpatch(1, nd, K) + (size_t)(item * nd + c) * gls(nd) + pair * (cw * nsq) + ci * nsq + a * nd + b;
+  return (size_t)p * gpatch(nd, K) + (size_t)(item * nd + c) * gls(nd) + pair * (cw * nsq) + ci * nsq + a * nd + b;
 }
 
-// G for every (patch slot, q), paired layout
-__global__ void geometry_kernel(long long nslots, int nd, int column, int K,
+// G for the patch slots [slot0, slot0 + nslots) and every q, paired layout (absolute positions:
+// in batch mode G points `slot0` slots before its buffer)
+__global__ void geometry_kernel(long long slot0, long long nslots, int nd, int K,
                                 const int32_t* __restrict__ pcell,
                                 const double* __restrict__ xgeom,
                                 const int32_t* __restrict__ geom_dofmap,
@@ -204,6 +202,7 @@ __global__ void geometry_kernel(long long nslots, int nd, int column, int K,
     return;
   long long slot = gid / nq;
   int q = (int)(gid - slot * nq);
+  slot += slot0;
   int c = pcell[slot];
   double g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0;
   if (c >= 0)
@@ -218,9 +217,9 @@ __global__ void geometry_kernel(long long nslots, int nd, int column, int K,
     g4 = (K[2][0] * K[1][0] + K[2][1] * K[1][1] + K[2][2] * K[1][2]) * s;
     g5 = (K[2][0] * K[2][0] + K[2][1] * K[2][1] + K[2][2] * K[2][2]) * s;
   }
-  G[gpos(column, nd, K, slot, q, 0)] = make_double2(g0, g1);
-  G[gpos(column, nd, K, slot, q, 1)] = make_double2(g2, g3);
-  G[gpos(column, nd, K, slot, q, 2)] = make_double2(g4, g5);
+  G[gpos(nd, K, slot, q, 0)] = make_double2(g0, g1);
+  G[gpos(nd, K, slot, q, 1)] = make_double2(g2, g3);
+  G[gpos(nd, K, slot, q, 2)] = make_double2(g4, g5);
 }
 
 // Constant geometry tensor of an affine cell: K K^T / detJ at the cell centre
@@ -273,7 +272,7 @@ __global__ void affine_geometry_kernel(long long nslots, const int32_t* __restri
 }
 
 // paired slot layout -> the reference's [cell][q][6]
-__global__ void geometry_export_kernel(long long nslots, int nd, int column, int K,
+__global__ void geometry_export_kernel(long long slot0, long long nslots, int nd, int K,
                                        const int32_t* __restrict__ pcell,
                                        const double2* __restrict__ G, double* __restrict__ out)
 {
@@ -283,11 +282,12 @@ __global__ void geometry_export_kernel(long long nslots, int nd, int column, int
     return;
   long long slot = gid / nq;
   int q = (int)(gid - slot * nq);
+  slot += slot0;
   int c = pcell[slot];
   if (c < 0)
     return;
-  double2 a = G[gpos(column, nd, K, slot, q, 0)], b = G[gpos(column, nd, K, slot, q, 1)],
-          d = G[gpos(column, nd, K, slot, q, 2)];
+  double2 a = G[gpos(nd, K, slot, q, 0)], b = G[gpos(nd, K, slot, q, 1)],
+          d = G[gpos(nd, K, slot, q, 2)];
   double* o = out + ((size_t)c * nq + q) * 6;
   o[0] = a.x;
   o[1] = a.y;
@@ -305,188 +305,6 @@ __global__ void geometry_export_kernel(long long nslots, int nd, int column, int
 __device__ __forceinline__ void lds_barrier()
 {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// ---- the hot kernel: y (+)= kappa * B^T G B x over the patches [first, first+gridDim) ----
-//
-// One workgroup per patch.  Phase 0 gathers the patch's x values (and, for dofs an
-// earlier colour already wrote, the y values to accumulate onto) into LDS; then
-// ROUNDS rounds each take CPR cells through the sum-factorised operator and add
-// their contributions into the LDS accumulator; the last phase writes the patch
-// dofs back.  The G stream of round r+1 is issued at the top of round r and stays
-// in flight across the LDS-only barriers (two rounds of operands are kept in flight).
-#ifndef PMG_BLOCK_WPS
-#define PMG_BLOCK_WPS 1
-#endif
-template <int P>
-__global__ void __launch_bounds__(Shape<P>::THREADS, PMG_BLOCK_WPS)
-    stiffness_kernel(const double* __restrict__ x, double* __restrict__ y,
-                     const double2* __restrict__ G, const int32_t* __restrict__ poff,
-                     const uint32_t* __restrict__ pdofs, const int32_t* __restrict__ lmap_id,
-                     const uint16_t* __restrict__ lmaps, const int32_t* __restrict__ pcell,
-                     const int32_t* __restrict__ pncell, const double* __restrict__ kappa,
-                     const double* __restrict__ Dg, int first, int atomic_out)
-{
-  using Sh = Shape<P>;
-  constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, CPR = Sh::CPR, ROUNDS = Sh::ROUNDS, NSQ = ND * ND;
-  constexpr int RN = Sh::RN, MAXM = Sh::MAXM, THREADS = Sh::THREADS, ITER = Sh::ITER;
-  __shared__ double sD[ND * ND];
-  __shared__ double skap[K];
-  __shared__ double sx[MAXM];
-  __shared__ double sy[MAXM];
-  __shared__ double su[RN];
-  __shared__ double sf0[RN];
-  __shared__ double sf1[RN];
-  __shared__ double sf2[RN];
-
-  const int p = first + blockIdx.x;
-  const int t = threadIdx.x;
-  // wave-uniform patch header: scalar loads
-  const int off = poff[p];
-  const int M = poff[p + 1] - off; // 1 <= M <= MAXM
-  const int table = lmap_id[p];
-  const int nc = pncell[p];
-  const int nrounds = (nc + CPR - 1) / CPR;
-
-  // position of this thread inside a round
-  const bool inr = t < RN;
-  const int tk = inr ? t : RN - 1;
-  const int lc = tk / N;
-  const int tl = tk - lc * N;
-  const uint16_t* lm = lmaps + (size_t)table * (K * N) + tk;
-  const double2* Gp = G + (size_t)p * K * 3 * N + (size_t)lc * 3 * N + tl;
-
-  // ---- phase 0: every load is unconditional (clamped index) so that the compiler
-  // can use counted vmcnt waits; the short loads that feed dependent loads go first.
-  int l_nxt[2];
-  double2 g01_nxt[2], g23_nxt[2], g45_nxt[2]; // operands of the next two rounds, in flight
-  {
-    uint32_t m[ITER];
-#pragma unroll
-    for (int k = 0; k < ITER; ++k)
-    {
-      const int i = t + k * THREADS;
-      m[k] = pdofs[off + (i < M ? i : M - 1)];
-    }
-    const int cellk = pcell[(size_t)p * K + (t < K ? t : K - 1)];
-    const double dval = Dg[t < ND * ND ? t : ND * ND - 1];
-    double xv[ITER], yv[ITER];
-#pragma unroll
-    for (int k = 0; k < ITER; ++k)
-    {
-      const uint32_t dof = m[k] & PD_MASK;
-      const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
-      xv[k] = x[dof];
-      const double* ya = acc ? (const double*)(y + dof) : (x + dof); // re-read of x keeps it unconditional
-      yv[k] = *ya;
-    }
-    const double kapk = kappa[cellk >= 0 ? cellk : 0];
-    // rounds 0 and 1 (empty slots hold zeros; the tables cover all K slots)
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-    {
-      const int rr = d < ROUNDS ? d : ROUNDS - 1;
-      l_nxt[d] = lm[rr * RN];
-      g01_nxt[d] = Gp[(size_t)rr * CPR * 3 * N];
-      g23_nxt[d] = Gp[(size_t)rr * CPR * 3 * N + N];
-      g45_nxt[d] = Gp[(size_t)rr * CPR * 3 * N + 2 * N];
-    }
-#pragma unroll
-    for (int k = 0; k < ITER; ++k)
-    {
-      const int i = t + k * THREADS;
-      if (i < M)
-      {
-        const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
-        sx[i] = (m[k] & PD_BC) ? 0.0 : xv[k]; // Dirichlet columns masked, src/laplacian.hpp:186-189
-        sy[i] = acc ? yv[k] : 0.0;
-      }
-    }
-    if (t < ND * ND)
-      sD[t] = dval;
-    if (t < K)
-      skap[t] = kapk;
-  }
-  lds_barrier();
-
-  const int a = tl / NSQ;
-  const int b = (tl - a * NSQ) / ND;
-  const int c = tl - a * NSQ - b * ND;
-
-#pragma unroll
-  for (int r = 0; r < ROUNDS; ++r)
-  {
-    if (r >= nrounds)
-      break;
-    const int l = l_nxt[r & 1];
-    const double2 g01 = g01_nxt[r & 1], g23 = g23_nxt[r & 1], g45 = g45_nxt[r & 1];
-    if (r + 2 < ROUNDS) // compile-time after unrolling: stream the operands of round r + 2
-    {
-      l_nxt[r & 1] = lm[(r + 2) * RN];
-      g01_nxt[r & 1] = Gp[(size_t)(r + 2) * CPR * 3 * N];
-      g23_nxt[r & 1] = Gp[(size_t)(r + 2) * CPR * 3 * N + N];
-      g45_nxt[r & 1] = Gp[(size_t)(r + 2) * CPR * 3 * N + 2 * N];
-    }
-    const bool active = inr && (r * CPR + lc < nc);
-    if (active)
-      su[t] = sx[l];
-    lds_barrier();
-    if (active)
-    {
-      const double kap = skap[r * CPR + lc];
-      const double* u = su + lc * N;
-      double vx = 0.0, vy = 0.0, vz = 0.0;
-#pragma unroll
-      for (int i = 0; i < ND; ++i)
-      {
-        vx += sD[a * ND + i] * u[i * NSQ + b * ND + c]; // :195-199
-        vy += sD[b * ND + i] * u[a * NSQ + i * ND + c]; // :206-210
-        vz += sD[c * ND + i] * u[a * NSQ + b * ND + i]; // :214-218
-      }
-      sf0[t] = kap * (g01.x * vx + g01.y * vy + g23.x * vz); // :233
-      sf1[t] = kap * (g01.y * vx + g23.y * vy + g45.x * vz); // :234
-      sf2[t] = kap * (g23.x * vx + g45.x * vy + g45.y * vz); // :235
-    }
-    lds_barrier();
-    if (active)
-    {
-      const double* f0 = sf0 + lc * N;
-      const double* f1 = sf1 + lc * N;
-      const double* f2 = sf2 + lc * N;
-      double wx = 0.0, wy = 0.0, wz = 0.0;
-#pragma unroll
-      for (int q = 0; q < ND; ++q)
-      {
-        wx += sD[q * ND + a] * f0[q * NSQ + b * ND + c]; // :246-251
-        wy += sD[q * ND + b] * f1[a * NSQ + q * ND + c]; // :255-259
-        wz += sD[q * ND + c] * f2[a * NSQ + b * ND + q]; // :263-267
-      }
-      atomicAdd(&sy[l], wx + wy + wz); // :270,277 -- in LDS (ds_add_f64)
-    }
-  }
-  lds_barrier();
-
-  // ---- write back: plain stores (the accumulator started from the earlier colours' y);
-  // the dof list is re-read (L2) rather than kept in registers across the rounds
-#pragma unroll
-  for (int k = 0; k < ITER; ++k)
-  {
-    const int i = t + k * THREADS;
-    if (i < M)
-    {
-      const uint32_t mk = pdofs[off + i];
-      const uint32_t dof = mk & PD_MASK;
-      if (mk & PD_BC)
-      {
-        if (!(mk & PD_ACC))
-          y[dof] = x[dof]; // :273-274
-      }
-      else if (atomic_out)
-        atomicAdd(&y[dof], sy[i]); // merged boundary launch (global_atomic_add_f64)
-      else
-        y[dof] = sy[i];
-    }
-  }
 }
 
 #ifdef PMG_STAMPS
@@ -693,7 +511,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
     double2 gq[AFF ? 1 : GD][3];
     double2 gfl[FLAT ? NJ : 1]; // flat layout: the next layer as loaded
     // (only used when FLAT; the item index is wave-uniform: a scalar base plus 32-bit lane offsets)
-    const double2* Gi = G + (size_t)p * gpatch(1, ND, K) + (size_t)__builtin_amdgcn_readfirstlane(it) * ND * LS;
+    const double2* Gi = G + (size_t)p * gpatch(ND, K) + (size_t)__builtin_amdgcn_readfirstlane(it) * ND * LS;
     int eo[FLAT ? NJ : 1]; // the lane's elements of a layer (clamped: the tail lanes re-read the last one)
     if constexpr (FLAT)
     {
@@ -861,7 +679,7 @@ __global__ void zero_list_kernel(int n, const int32_t* __restrict__ idx, double*
 }
 
 // ---- matrix-free diagonal (replaces the CSR detour of examples/pmg/main.cpp:274-279) ----
-__global__ void diagonal_kernel(long long nslots, int nd, int column, int K,
+__global__ void diagonal_kernel(long long slot0, long long nslots, int nd, int K,
                                 const int32_t* __restrict__ pcell,
                                 const double2* __restrict__ G, const int32_t* __restrict__ dofmap,
                                 const int8_t* __restrict__ bc, const double* __restrict__ kappa,
@@ -873,11 +691,12 @@ __global__ void diagonal_kernel(long long nslots, int nd, int column, int K,
     return;
   long long slot = gid / N;
   int t = (int)(gid - slot * N);
+  slot += slot0;
   int cell = pcell[slot];
   if (cell < 0)
     return;
   int a = t / nsq, b = (t - a * nsq) / nd, c = t - a * nsq - b * nd;
-  auto Gq = [&](int q, int pair) { return G[gpos(column, nd, K, slot, q, pair)]; };
+  auto Gq = [&](int q, int pair) { return G[gpos(nd, K, slot, q, pair)]; };
   double s = 0.0;
   for (int q = 0; q < nd; ++q)
   {
@@ -929,28 +748,63 @@ __global__ void rhs_kernel(long long nslots, int nq, const int32_t* __restrict__
   atomicAdd(&b[dof], kappa[c] * w[q] * detJ * f[dof]);
 }
 
+// geometry of the patches [first, first + count) into the (batch) buffer; returns the base pointer
+// to hand to kernels that index G by absolute patch slot
+const double2* batch_geometry(pmg_laplacian op, int first, int count, hipStream_t s)
+{
+  double2* base = op->G - (size_t)first * gpatch(op->nd, op->K);
+  const long long nslots = (long long)count * op->K, n = nslots * op->N;
+  if (n > 0)
+    geometry_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((long long)first * op->K, nslots, op->nd, op->K,
+                                                              op->pcell, op->xgeom, op->geom_dofmap,
+                                                              op->dphi_geom, op->gweights, base);
+  return base;
+}
+
+// f(first patch, patch count, G base) over all patches: once with the resident tensor, or batch by
+// batch with the tensor recomputed into the batch buffer
+template <typename F>
+int for_each_geometry_chunk(pmg_laplacian op, hipStream_t s, F f)
+{
+  if (op->npatch == 0)
+    return PMG_OK;
+  if (op->batch_patches <= 0)
+    f(0, op->npatch, op->G);
+  else
+    for (int first = 0; first < op->npatch; first += op->batch_patches)
+    {
+      const int count = std::min(op->batch_patches, op->npatch - first);
+      f(first, count, batch_geometry(op, first, count, s));
+    }
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
 template <int P>
 int launch_stiffness(pmg_laplacian op, const double* x, double* y, int first, int count,
                      int atomic_out, hipStream_t s)
 {
   if (count <= 0)
     return PMG_OK;
-  if constexpr (column_layout(P))
+  if (op->batch_patches > 0 && op->geometry_mode == 0 && count > op->batch_patches)
+  {
+    for (int f = first; f < first + count; f += op->batch_patches) // :384-412
+      PMG_TRY(launch_stiffness<P>(op, x, y, f, std::min(op->batch_patches, first + count - f), atomic_out, s));
+    return PMG_OK;
+  }
+  const double2* G = op->G;
+  if (op->batch_patches > 0 && op->geometry_mode == 0)
+    G = batch_geometry(op, first, count, s); // :391-396
   {
     if (op->geometry_mode == 1)
       stiffness_column_kernel<P, true><<<count, Shape<P>::WTHREADS, 0, s>>>(
-          x, y, op->G, op->Gaff, op->W1, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell,
+          x, y, G, op->Gaff, op->W1, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell,
           op->pncell, op->kappa, op->D, first, atomic_out);
     else
       stiffness_column_kernel<P, false><<<count, Shape<P>::WTHREADS, 0, s>>>(
-          x, y, op->G, op->Gaff, op->W1, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell,
+          x, y, G, op->Gaff, op->W1, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell,
           op->pncell, op->kappa, op->D, first, atomic_out);
   }
-  else
-    stiffness_kernel<P><<<count, Shape<P>::THREADS, 0, s>>>(x, y, op->G, op->poff, op->pdofs,
-                                                            op->lmap_id, op->lmaps, op->pcell,
-                                                            op->pncell, op->kappa, op->D, first,
-                                                            atomic_out);
   op->launches++;
   return PMG_OK;
 }
@@ -1033,6 +887,16 @@ int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s);
 const double* laplacian_diag_inv(pmg_laplacian op) { return op->diag_inv; }
 pmg_layout laplacian_layout(pmg_laplacian op) { return op->layout; }
 long long laplacian_launches(pmg_laplacian op) { return op->applies; }
+struct LaplacianInputs
+{
+  int degree;
+  int32_t ncells;
+  const int32_t* dofmap;
+  const int8_t* bc;
+  const double* kappa;
+};
+LaplacianInputs laplacian_inputs(pmg_laplacian op) { return {op->P, op->ncells, op->dofmap, op->bc, op->kappa}; }
+
 PatchView laplacian_patches(pmg_laplacian op)
 {
   PatchView v;
@@ -1041,7 +905,6 @@ PatchView laplacian_patches(pmg_laplacian op)
   v.N = op->N;
   v.npatch = op->npatch;
   v.max_m = op->max_m;
-  v.column = column_layout(op->P);
   v.pcell_h = &op->pcell_h;
   v.pncell_h = &op->pncell_h;
   v.launch_first = &op->launch_first;
@@ -1263,7 +1126,7 @@ extern "C" int pmg_laplacian_create_with_tables(
     affine_geometry_kernel<<<(unsigned)((nslots + 255) / 256), 256, 0, s>>>(nslots, op->pcell, xgeom,
                                                                            geom_dofmap, op->Gaff);
   {
-    const size_t gsize = (size_t)op->npatch * gpatch(column_layout(degree) ? 1 : 0, nd, op->K);
+    const size_t gsize = (size_t)op->npatch * gpatch(nd, op->K);
     PMG_HIP(hipMalloc(&op->G, sizeof(double2) * (gsize ? gsize : 1)));
     PMG_HIP(hipMemsetAsync(op->G, 0, sizeof(double2) * (gsize ? gsize : 1), s)); // padding, empty slots
   }
@@ -1272,10 +1135,7 @@ extern "C" int pmg_laplacian_create_with_tables(
   PMG_HIP(hipEventCreate(&op->ev1));
   if (nq_total > 0)
   {
-    long long blocks = (nq_total + 255) / 256;
-    geometry_kernel<<<(unsigned)blocks, 256, 0, s>>>(nslots, nd, column_layout(degree) ? 1 : 0, op->K,
-                                                    op->pcell, xgeom, geom_dofmap, op->dphi_geom,
-                                                    op->gweights, op->G);
+    batch_geometry(op, 0, op->npatch, s);
     PMG_HIP(hipGetLastError());
   }
   PMG_HIP(hipStreamSynchronize(s)); // plan's host vectors are released on return
@@ -1333,7 +1193,6 @@ extern "C" int pmg_laplacian_set_geometry_mode(pmg_laplacian op, int mode)
   if (mode == 1)
   {
     PMG_REQUIRE(op->all_affine, "pmg_laplacian_set_geometry_mode: the mesh has non-affine cells");
-    PMG_REQUIRE(column_layout(op->P), "pmg_laplacian_set_geometry_mode: affine mode needs the column kernel");
   }
   op->geometry_mode = mode;
   return PMG_OK;
@@ -1372,12 +1231,12 @@ extern "C" int pmg_laplacian_compute_diag_inverse(pmg_laplacian op, pmg_stream s
   hipStream_t s = S(stream);
   const int total = op->layout->total();
   PMG_HIP(hipMemsetAsync(op->diag_inv, 0, sizeof(double) * total, s));
-  const long long nslots = (long long)op->npatch * op->K;
-  const long long n = nslots * op->N;
-  if (n > 0)
-    diagonal_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
-        nslots, op->nd, column_layout(op->P) ? 1 : 0, op->K, op->pcell, op->G, op->dofmap, op->bc,
-        op->kappa, op->D, op->diag_inv);
+  PMG_TRY(for_each_geometry_chunk(op, s, [&](int first, int count, const double2* G) {
+    const long long nslots = (long long)count * op->K, n = nslots * op->N;
+    diagonal_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((long long)first * op->K, nslots, op->nd, op->K,
+                                                              op->pcell, G, op->dofmap, op->bc, op->kappa, op->D,
+                                                              op->diag_inv);
+  }));
   if (total > 0)
     diag_invert_kernel<<<(total + 255) / 256, 256, 0, s>>>(total, op->bc, op->diag_inv);
   PMG_HIP(hipGetLastError());
@@ -1390,11 +1249,11 @@ extern "C" int pmg_laplacian_get_geometry(pmg_laplacian op, double* G_out, pmg_s
   PMG_REQUIRE(op && G_out, "pmg_laplacian_get_geometry: NULL argument");
   hipStream_t s = S(stream);
   PMG_HIP(hipMemsetAsync(G_out, 0, sizeof(double) * 6 * (size_t)op->ncells * op->N, s));
-  const long long nslots = (long long)op->npatch * op->K;
-  const long long n = nslots * op->N;
-  if (n > 0)
-    geometry_export_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(
-        nslots, op->nd, column_layout(op->P) ? 1 : 0, op->K, op->pcell, op->G, G_out);
+  PMG_TRY(for_each_geometry_chunk(op, s, [&](int first, int count, const double2* G) {
+    const long long nslots = (long long)count * op->K, n = nslots * op->N;
+    geometry_export_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((long long)first * op->K, nslots, op->nd,
+                                                                     op->K, op->pcell, G, G_out);
+  }));
   PMG_HIP(hipGetLastError());
   return PMG_OK;
 }
@@ -1435,6 +1294,42 @@ extern "C" int pmg_laplacian_time_kernel(pmg_laplacian op, const double* in, dou
   PMG_HIP(hipEventElapsedTime(&ms, op->ev0, op->ev1));
   *ms_per_launch = (double)ms / reps / nl;
   return PMG_OK;
+}
+
+// src/laplacian.hpp:383-396 (examples/mat_free/main.cpp:34-50 --batch_size)
+extern "C" int pmg_laplacian_set_geometry_batch(pmg_laplacian op, long long batch_cells)
+{
+  PMG_REQUIRE(op && batch_cells >= 0, "pmg_laplacian_set_geometry_batch: bad argument");
+  int32_t bp = 0;
+  if (batch_cells > 0)
+  {
+    const long long want = (batch_cells + op->K - 1) / op->K;
+    bp = (int32_t)std::min<long long>(std::max<long long>(want, 1), std::max(op->npatch, 1));
+  }
+  if (bp == op->batch_patches)
+    return PMG_OK;
+  PMG_HIP(hipDeviceSynchronize()); // nothing may still read the tensor
+  (void)hipFree(op->G);
+  op->G = nullptr;
+  const size_t per_patch = (size_t)gpatch(op->nd, op->K);
+  const size_t gsize = per_patch * (size_t)(bp > 0 ? bp : op->npatch);
+  PMG_HIP(hipMalloc(&op->G, sizeof(double2) * (gsize ? gsize : 1)));
+  PMG_HIP(hipMemset(op->G, 0, sizeof(double2) * (gsize ? gsize : 1))); // padding of the flat layout
+  op->batch_patches = bp;
+  if (bp == 0 && op->npatch > 0) // back to the resident tensor
+  {
+    batch_geometry(op, 0, op->npatch, nullptr);
+    PMG_HIP(hipGetLastError());
+    PMG_HIP(hipDeviceSynchronize());
+  }
+  return PMG_OK;
+}
+
+extern "C" long long pmg_laplacian_geometry_bytes(pmg_laplacian op)
+{
+  if (!op)
+    return -1;
+  return (long long)sizeof(double2) * gpatch(op->nd, op->K) * (op->batch_patches > 0 ? op->batch_patches : op->npatch);
 }
 
 extern "C" int pmg_laplacian_set_profiling(pmg_laplacian op, int flag)

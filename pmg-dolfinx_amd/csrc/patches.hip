@@ -164,7 +164,6 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
   const PatchShape shp = patch_shape(P);
   const int K = shp.K();
   const int nd = P + 1, N = nd * nd * nd;
-  const bool column = column_layout(P);
   plan = PatchPlan();
   plan.K = K;
   plan.N = N;
@@ -239,7 +238,7 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
     {
       const int32_t* dm = dofmap + (size_t)t.cells[s] * N;
       for (int k = 0; k < N; ++k)
-        t.lmap[s * N + table_index(column, nd, k)]
+        t.lmap[s * N + table_index(nd, k)]
             = (uint16_t)(std::lower_bound(t.dofs.begin(), t.dofs.end(), dm[k]) - t.dofs.begin());
     }
     plan.max_M = std::max(plan.max_M, (int)t.dofs.size());

@@ -10,8 +10,9 @@
 // patch dof once.  Patches are coloured so that no two patches of a colour share
 // a dof; colours are launched one after the other on the stream, so the write is
 // a plain store for the first patch that touches a dof and a plain
-// read-modify-write for the later ones: no atomics, no zero-fill of y, and a
-// run-to-run deterministic result.
+// read-modify-write for the later ones: no global atomics and no zero-fill of y
+// (inside a patch the cell sums meet in LDS in arrival order, so two runs agree
+// to rounding, not bit for bit).
 #pragma once
 
 #include "common.hpp"
@@ -27,70 +28,42 @@ constexpr uint32_t PD_MASK = 0x3fffffffu;
 
 // Patch geometry per degree: a block of bx*by*bz cells on a tensor grid (long in
 // z, the direction in which a lexicographic dof numbering is contiguous, so the
-// patch's x gather / y store move long runs), processed by one workgroup in
-// `rounds` rounds of `cpr` cells.  max_m bounds the number of distinct dofs of a
+// patch's x gather / y store move long runs), processed by one workgroup.  max_m bounds the number of distinct dofs of a
 // patch (LDS size of the kernel); the builder closes a patch early rather than
 // exceed it, so any mesh and any cell order is handled.
 struct PatchShape
 {
   int bx, by, bz; // cells per patch along x, y, z
-  int cpr;        // cells per round
   int max_m;      // LDS capacity in dofs
   int K() const { return bx * by * bz; }
-  int rounds() const { return (K() + cpr - 1) / cpr; }
 };
 inline constexpr PatchShape patch_shape(int P)
 {
   switch (P)
   {
   case 1:
-#ifdef PMG_P1_SHAPE
-    return PMG_P1_SHAPE; // tuning build
-#else
-    return {4, 4, 8, 32, 256};   // M = 5*5*9   = 225
-#endif
+    return {4, 4, 8, 256};   // M = 5*5*9   = 225
   case 2:
-#ifdef PMG_P2_SHAPE
-    return PMG_P2_SHAPE; // tuning build
-#else
-    return {4, 4, 8, 8, 1408};   // M = 9*9*17  = 1377 (measured 12 % faster than 2x2x8)
-#endif
+    return {4, 4, 8, 1408};   // M = 9*9*17  = 1377 (measured 12 % faster than 2x2x8)
   case 3:
-    return {2, 2, 8, 4, 1280};   // M = 7*7*25  = 1225
+    return {2, 2, 8, 1280};   // M = 7*7*25  = 1225
   case 4:
-#if defined(PMG_P4_SHAPE)
-    return PMG_P4_SHAPE; // tuning build
-#elif defined(PMG_P4_BZ4)
-    return {2, 2, 4, 4, 1408};   // M = 9*9*17  = 1377 (tuning build)
-#else
-    return {2, 2, 8, 4, 2688};   // M = 9*9*33  = 2673
-#endif
+    return {2, 2, 8, 2688};   // M = 9*9*33  = 2673
   case 5:
-    return {2, 2, 4, 2, 2560};   // M = 11*11*21 = 2541
+    return {2, 2, 4, 2560};   // M = 11*11*21 = 2541
   case 6:
-    return {2, 2, 2, 1, 2240};   // M = 13^3    = 2197
+    return {2, 2, 2, 2240};   // M = 13^3    = 2197
   case 7:
-    return {2, 2, 2, 1, 3392};   // M = 15^3    = 3375
+    return {2, 2, 2, 3392};   // M = 15^3    = 3375
   default:
-    return {1, 1, 4, 1, 2688};   // M = 9*9*33  = 2673
+    return {1, 1, 4, 2688};   // M = 9*9*33  = 2673
   }
 }
 
-// Two kernel families consume the patches.  "column" (the default for every
-// degree): a wavefront takes whole cells -- at P = 8, where the 81 columns do not
-// fit 64 lanes, two wavefronts share a cell -- and a lane owns the column of nd
-// points above (a, b); the per-cell tables are then stored layer by layer, index
-// c*nd^2 + a*nd + b.  "block" (degrees above PMG_COLUMN_MAX; kept as the
-// alternative build -DPMG_COLUMN_MAX=7 for P = 8): one thread per (cell, dof),
-// tables in the dofmap order t = a*nd^2 + b*nd + c.
-#ifndef PMG_COLUMN_MAX
-#define PMG_COLUMN_MAX 8
-#endif
-inline constexpr bool column_layout(int P) { return P <= PMG_COLUMN_MAX; }
-inline int table_index(bool column, int nd, int t)
+// The per-cell tables are stored layer by layer (the stiffness kernel marches along c):
+// index c*nd^2 + a*nd + b for the dofmap's t = a*nd^2 + b*nd + c.
+inline int table_index(int nd, int t)
 {
-  if (!column)
-    return t;
   const int a = t / (nd * nd), b = (t / nd) % nd, c = t % nd;
   return c * nd * nd + a * nd + b;
 }
@@ -125,7 +98,6 @@ struct PatchPlan
 struct PatchView
 {
   int P = 0, K = 0, N = 0, npatch = 0, max_m = 0;
-  bool column = false;
   // host copies
   const std::vector<int32_t>* pcell_h = nullptr;  // [npatch*K]
   const std::vector<int32_t>* pncell_h = nullptr; // [npatch]

@@ -27,6 +27,8 @@ int interp_prolong(pmg_interpolator ip, double* coarse, double* fine, hipStream_
 int interp_restrict(pmg_interpolator ip, double* fine, double* coarse, hipStream_t s);
 int interp_prolong_add(pmg_interpolator ip, double* coarse, double* fine, hipStream_t s);
 bool interp_is_patched(pmg_interpolator ip);
+int amg_solve(pmg_amg amg, double* x, const double* b, hipStream_t s);
+pmg_layout amg_layout(pmg_amg amg);
 void launch_cheb_first(int n, double* x, double* r, double* z, const double* q, const double* dinv,
                        double c1, double c2, hipStream_t s);
 } // namespace pmg
@@ -65,7 +67,55 @@ struct pmg_multigrid_s
   pmg_cg coarse = nullptr;
   pmg_coarse_solve_fn coarse_fn = nullptr;
   void* coarse_user = nullptr;
+  pmg_amg coarse_amg = nullptr;
 };
+
+namespace pmg
+{
+// src/chebyshev.hpp:46-91.
+//   need_r : keep r = b - A x current on exit (costs the loop's last apply)
+//   x_zero : x is known to be 0 on entry (A 0 = 0, so r = b and x := z)
+int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n, double lmax, int max_iter,
+                 double* x, const double* b, bool need_r, bool x_zero, hipStream_t s)
+{
+  const double c0 = 4.0 / (3.0 * lmax);
+  if (x_zero)
+    launch_cheb_init(n, w.r, w.z, b, nullptr, dinv, c0, s);
+  else
+  {
+    PMG_TRY(A(x, w.q));                                  // :56
+    launch_cheb_init(n, w.r, w.z, b, w.q, dinv, c0, s); // :57,67-68
+  }
+  for (int i = 1; i <= max_iter; ++i)
+  {
+    const bool last = (i == max_iter);
+    if (last && !need_r)
+    {
+      if (x_zero && i == 1)
+        PMG_HIP(hipMemcpyAsync(x, w.z, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+      else
+        launch_add(n, x, w.z, s); // :73
+      break;
+    }
+    PMG_TRY(A(w.z, w.q)); // :76
+    if (last) // need_r: the new z would not be used, only x and r are (:73,77)
+    {
+      launch_cheb_last(n, x, w.r, w.z, w.q, x_zero && i == 1, s);
+      break;
+    }
+    const double c1 = (2.0 * i - 1.0) / (2.0 * i + 3.0);
+    const double c2 = (8.0 * i + 4.0) / (2.0 * i + 3.0) / lmax;
+    if (x_zero && i == 1)
+      launch_cheb_first(n, x, w.r, w.z, w.q, dinv, c1, c2, s);
+    else
+      launch_cheb_step(n, x, w.r, w.z, w.q, dinv, c1, c2, s); // :73,77,80-83
+  }
+  if (max_iter == 0 && x_zero)
+    PMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * n, s));
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+} // namespace pmg
 
 namespace
 {
@@ -77,53 +127,17 @@ int alloc_vec(pmg_layout l, double** p)
   return PMG_OK;
 }
 
-// src/chebyshev.hpp:46-91.
-//   need_r : keep r = b - A x current on exit (costs the loop's last apply)
-//   x_zero : x is known to be 0 on entry (A 0 = 0, so r = b and x := z)
+// src/chebyshev.hpp:46-91 on the operator `A` (see cheb_iterate)
 int cheb_solve(pmg_chebyshev sm, pmg_laplacian A, double* x, const double* b, bool need_r,
                bool x_zero, hipStream_t s)
 {
   pmg_layout l = sm->layout;
   PMG_REQUIRE(laplacian_layout(A) == l, "Chebyshev: operator and smoother layouts differ");
-  const int n = l->size_local;
-  const double lmax = sm->eig_max; // eig_range[0] is unused, src/chebyshev.hpp:51
-  const double* dinv = laplacian_diag_inv(A); // no per-call D2D copy (:53)
-  const double c0 = 4.0 / (3.0 * lmax);
-  if (x_zero)
-    launch_cheb_init(n, sm->r, sm->z, b, nullptr, dinv, c0, s);
-  else
-  {
-    PMG_TRY(laplacian_apply(A, x, sm->q, s));               // :56
-    launch_cheb_init(n, sm->r, sm->z, b, sm->q, dinv, c0, s); // :57,67-68
-  }
-  for (int i = 1; i <= sm->max_iter; ++i)
-  {
-    const bool last = (i == sm->max_iter);
-    if (last && !need_r)
-    {
-      if (x_zero && i == 1)
-        PMG_HIP(hipMemcpyAsync(x, sm->z, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-      else
-        launch_add(n, x, sm->z, s); // :73
-      break;
-    }
-    PMG_TRY(laplacian_apply(A, sm->z, sm->q, s)); // :76
-    if (last) // need_r: the new z would not be used, only x and r are (:73,77)
-    {
-      launch_cheb_last(n, x, sm->r, sm->z, sm->q, x_zero && i == 1, s);
-      break;
-    }
-    const double c1 = (2.0 * i - 1.0) / (2.0 * i + 3.0);
-    const double c2 = (8.0 * i + 4.0) / (2.0 * i + 3.0) / lmax;
-    if (x_zero && i == 1)
-      launch_cheb_first(n, x, sm->r, sm->z, sm->q, dinv, c1, c2, s);
-    else
-      launch_cheb_step(n, x, sm->r, sm->z, sm->q, dinv, c1, c2, s); // :73,77,80-83
-  }
-  if (sm->max_iter == 0 && x_zero)
-    PMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * n, s));
-  PMG_HIP(hipGetLastError());
-  return PMG_OK;
+  const ChebWork w{sm->r, sm->z, sm->q};
+  // eig_range[0] is unused (src/chebyshev.hpp:51); no per-call D2D copy of the diagonal (:53)
+  return cheb_iterate(
+      w, [A, s](double* in, double* out) { return laplacian_apply(A, in, out, s); }, laplacian_diag_inv(A),
+      l->size_local, sm->eig_max, sm->max_iter, x, b, need_r, x_zero, s);
 }
 
 // src/pmg.hpp:56-155 (lean form, see the file header)
@@ -157,7 +171,9 @@ int mg_apply(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStr
     Range rg("pmg:coarse_solve");
     const double* b0 = (L == 1) ? rhs : mg->b[0];
     const bool zero = (L == 1) ? y_zero : true;
-    if ((mg->coarse || mg->coarse_fn) && L > 1) // :106-107, KSP-style: zero initial guess
+    if (mg->coarse_amg && L > 1) // :106-107 with the library's own AMG (amg.hip)
+      PMG_TRY(amg_solve(mg->coarse_amg, mg->u[0], mg->b[0], s));
+    else if ((mg->coarse || mg->coarse_fn) && L > 1) // :106-107, KSP-style: zero initial guess
     {
       PMG_HIP(hipMemsetAsync(mg->u[0], 0, sizeof(double) * mg->layouts[0]->total(), s));
       if (mg->coarse_fn)
@@ -291,32 +307,30 @@ extern "C" int pmg_cg_store_coefficients(pmg_cg cg, int flag)
   return PMG_OK;
 }
 
-// src/cg.hpp:147-222
-extern "C" int pmg_cg_solve(pmg_cg cg, pmg_laplacian A, double* x, const double* b,
-                            pmg_multigrid precond, int* iterations, pmg_stream stream)
+namespace pmg
 {
-  PMG_REQUIRE(cg && A && x && b, "pmg_cg_solve: NULL argument");
+// src/cg.hpp:147-222 over any operator `A`; the preconditioner is `M` (z = M r) if given, else the
+// diagonal `dinv` (the reference's hard-wired Jacobi, :161,192).
+int cg_iterate(pmg_cg cg, const ApplyFn& A, const double* dinv, const PrecondFn* M, bool flexible, double* x,
+               const double* b, int* iterations, hipStream_t s)
+{
   pmg_layout l = cg->layout;
-  PMG_REQUIRE(laplacian_layout(A) == l, "pmg_cg_solve: operator and solver layouts differ");
-  hipStream_t s = S(stream);
   const int n = l->size_local;
-  const double* dinv = laplacian_diag_inv(A); // :154
   double *r = cg->r, *y = cg->y, *p = cg->p;
-
+  const bool precond = M != nullptr;
   auto precondition = [&](double* out_z, const double* in_r) -> int
   {
-    if (precond) // zero initial guess: folded into the smoothers' x_zero path, no memset of out_z
-      return mg_apply(precond, in_r, out_z, true, s);
+    if (precond)
+      return (*M)(out_z, in_r);
     launch_pointwise(n, out_z, in_r, dinv, s); // :161,192
     return PMG_OK;
   };
-
   // Flexible CG (Polak-Ribiere beta) for a preconditioner that is not a fixed linear operator --
   // the V-cycle with a Krylov coarse solver: one more vector (the previous z), one more dot product
-  const bool flex = cg->flexible && precond;
+  const bool flex = flexible && precond;
   if (flex && !cg->zold)
     PMG_TRY(alloc_vec(l, &cg->zold));
-  PMG_TRY(laplacian_apply(A, x, y, s)); // :159
+  PMG_TRY(A(x, y)); // :159
   launch_axpy(n, r, -1.0, y, b, s);     // :160
   PMG_TRY(precondition(p, r));          // :161
   if (flex)
@@ -325,6 +339,13 @@ extern "C" int pmg_cg_solve(pmg_cg cg, pmg_laplacian A, double* x, const double*
   PMG_TRY(dot_host(l, p, r, &rnorm0, s)); // :163
   double rnorm = rnorm0;
   const double rtol2 = cg->rtol * cg->rtol;
+  if (!(rnorm0 > 0.0)) // r = 0 (or not finite): x already solves the system; :206 would divide by zero
+  {
+    if (iterations)
+      *iterations = 0;
+    cg->residuals.assign(1, rnorm0);
+    return PMG_OK;
+  }
   // The loop keeps its scalars on the device: p.y, r.z (and r.z_old) are reduced there (one
   // ncclAllReduce each when the layout has a communicator), alpha and beta are formed inside the
   // update kernels, and the host reads the values ONCE per iteration, at its end, for the stopping
@@ -335,7 +356,7 @@ extern "C" int pmg_cg_solve(pmg_cg cg, pmg_laplacian A, double* x, const double*
   {
     ++k;
     Range range("pmg:cg_iteration"); // src/cg.hpp:174,219
-    PMG_TRY(laplacian_apply(A, p, y, s)); // :179
+    PMG_TRY(A(p, y)); // :179
     PMG_TRY(dot_async(l, p, y, 1, s));
     PMG_TRY(reduce_slots_async(l, 1, 1, false, s));
     if (precond)
@@ -379,6 +400,19 @@ extern "C" int pmg_cg_solve(pmg_cg cg, pmg_laplacian A, double* x, const double*
     *iterations = k;
   PMG_HIP(hipGetLastError());
   return PMG_OK;
+}
+} // namespace pmg
+
+extern "C" int pmg_cg_solve(pmg_cg cg, pmg_laplacian A, double* x, const double* b,
+                            pmg_multigrid precond, int* iterations, pmg_stream stream)
+{
+  PMG_REQUIRE(cg && A && x && b, "pmg_cg_solve: NULL argument");
+  PMG_REQUIRE(laplacian_layout(A) == cg->layout, "pmg_cg_solve: operator and solver layouts differ");
+  hipStream_t s = S(stream);
+  const ApplyFn apply = [A, s](double* in, double* out) { return laplacian_apply(A, in, out, s); };
+  // the V-cycle from a zero initial guess: folded into the smoothers' x_zero path, no memset of z
+  const PrecondFn vcycle = [precond, s](double* z, const double* r) { return mg_apply(precond, r, z, true, s); };
+  return cg_iterate(cg, apply, laplacian_diag_inv(A), precond ? &vcycle : nullptr, cg->flexible, x, b, iterations, s);
 }
 
 extern "C" int pmg_cg_set_flexible(pmg_cg cg, int flag)
@@ -464,6 +498,21 @@ extern "C" int pmg_multigrid_set_coarse_solver(pmg_multigrid mg, pmg_cg coarse)
               "pmg_multigrid_set_coarse_solver: the solver is not on the coarsest layout");
   mg->coarse = coarse;
   mg->coarse_fn = nullptr;
+  mg->coarse_amg = nullptr;
+  return PMG_OK;
+}
+
+extern "C" int pmg_multigrid_set_coarse_amg(pmg_multigrid mg, pmg_amg amg)
+{
+  PMG_REQUIRE(mg, "pmg_multigrid_set_coarse_amg: NULL argument");
+  PMG_REQUIRE(!amg || amg_layout(amg) == mg->layouts[0],
+              "pmg_multigrid_set_coarse_amg: the solver is not on the coarsest layout");
+  mg->coarse_amg = amg;
+  if (amg)
+  {
+    mg->coarse = nullptr;
+    mg->coarse_fn = nullptr;
+  }
   return PMG_OK;
 }
 
@@ -473,7 +522,10 @@ extern "C" int pmg_multigrid_set_coarse_callback(pmg_multigrid mg, pmg_coarse_so
   mg->coarse_fn = solve;
   mg->coarse_user = user;
   if (solve)
+  {
     mg->coarse = nullptr;
+    mg->coarse_amg = nullptr;
+  }
   return PMG_OK;
 }
 

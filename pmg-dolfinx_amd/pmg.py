@@ -41,17 +41,47 @@ class MultigridPreconditioner:
         self._set("pmg_multigrid_set_interpolators", interpolators, "interpolators")
 
     def set_coarse_solver(self, solver):  # :46
-        """``solver``: a :class:`CGSolver` on the coarsest layout (its iteration cap and tolerance
-        apply; zero initial guess, like the reference's KSP solve) or ``None`` for the smoother
-        (``src/pmg.hpp:106-109``).  The reference's coarse solver is PETSc KSPCG + hypre BoomerAMG
-        (``src/amg.hpp``); the AMG preconditioner is third-party and out of scope, the Krylov
-        method here is the library's Jacobi-preconditioned CG."""
+        """The reference's CoarseSolver concept is "anything with ``solve(x, b)``" (``src/amg.hpp:67``,
+        called at ``src/pmg.hpp:106-107``); ``None`` restores the level-0 smoother (``:108-109``).
+        Wired natively: :class:`AmgSolver` (the library's AMG, the role of hypre BoomerAMG + KSPCG in
+        the reference) and :class:`CGSolver` (Jacobi-preconditioned, its iteration cap and tolerance
+        apply, zero initial guess).  Any other object with ``solve(Vector, Vector)`` is called back
+        from inside the cycle on two vectors of the coarsest layout."""
+        from .amg import AmgSolver
         from .cg import CGSolver
 
-        if solver is not None and not isinstance(solver, CGSolver):
-            raise TypeError("the coarse solver must be a CGSolver (hypre/PETSc AMG is out of scope) or None")
         self._keep["coarse"] = solver
-        call("pmg_multigrid_set_coarse_solver", self._handle, solver.handle if solver is not None else None)
+        if solver is None:
+            call("pmg_multigrid_set_coarse_callback", self._handle, _lib.COARSE_FN(), None)
+            call("pmg_multigrid_set_coarse_solver", self._handle, None)
+            call("pmg_multigrid_set_coarse_amg", self._handle, None)
+        elif isinstance(solver, AmgSolver):
+            call("pmg_multigrid_set_coarse_amg", self._handle, solver.handle)
+        elif isinstance(solver, CGSolver):
+            call("pmg_multigrid_set_coarse_solver", self._handle, solver.handle)
+        elif hasattr(solver, "solve"):
+            cx, cb = Vector(self.layouts[0]), Vector(self.layouts[0])
+            lay = self.layouts[0].handle
+
+            def bridge(user, x, b, stream):
+                try:  # owned entries in and out with the library's own copy kernel, on the cycle's stream
+                    call("pmg_vec_copy", lay, ptr(cb.data), vp(b), vp(stream))
+                    call("pmg_vec_copy", lay, ptr(cx.data), vp(x), vp(stream))
+                    solver.solve(cx, cb)
+                    call("pmg_vec_copy", lay, vp(x), ptr(cx.data), vp(stream))
+                    return 0
+                except Exception:  # never let an exception cross the C boundary
+                    import sys
+                    import traceback
+
+                    traceback.print_exc(file=sys.stderr)
+                    return 1
+
+            self._keep["coarse_cb"] = _lib.COARSE_FN(bridge)
+            self._keep["coarse_vecs"] = (cx, cb)
+            call("pmg_multigrid_set_coarse_callback", self._handle, self._keep["coarse_cb"], None)
+        else:
+            raise TypeError("the coarse solver needs a solve(x, b) method")
 
     def apply(self, x: Vector, y: Vector, verbose: bool = False):  # :56-155
         """``x`` is the right-hand side, ``y`` the initial guess on entry and the

@@ -1,0 +1,200 @@
+"""The library's algebraic multigrid for the degree-1 level (csrc/amg.hip; the slot of the reference's
+CoarseSolverType<T> = PETSc KSPCG + hypre BoomerAMG, src/amg.hpp).  Parity with the reference is
+unpinned here (third-party arithmetic, no fixture); these tests pin the set-up against first
+principles, the device cycle against a numpy restatement on the same hierarchy, and the solver's
+defining properties."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def twist(x):
+    y = x.copy()
+    y[:, 0] += 0.12 * x[:, 1] * x[:, 2]
+    y[:, 1] += 0.10 * x[:, 0] * x[:, 2] + 0.05 * x[:, 0] * x[:, 1] * x[:, 2]
+    y[:, 2] += 0.08 * x[:, 0] * x[:, 1]
+    return y
+
+
+@pytest.fixture(scope="module")
+def pm(built):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pmg_dolfinx_amd as pm
+
+    torch.cuda.set_device(0)
+    return pm
+
+
+def _p1(pm, n, warp=twist, kappa=2.0):
+    part = pm.BoxPartition(n, warp=warp)
+    lv = part.level(1)
+    layout = pm.make_layout(lv)
+    op = pm.MatFreeLaplacian(1, kappa, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells, lv.bc_marker,
+                             layout)
+    op.compute_diag_inverse()
+    return part, lv, layout, op
+
+
+def _vec(pm, layout, a):
+    v = pm.Vector(layout)
+    v.data.copy_(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)))
+    return v
+
+
+def test_hierarchy_against_first_principles(pm):
+    from oracle import pmg_oracle as po
+
+    n = 14
+    part, lv, layout, op = _p1(pm, n)
+    amg = pm.AmgSolver(op)
+    L = amg.num_levels()
+    assert L >= 2 and amg.level_info(L - 1)["rows"] <= 800
+    # level 0 is the operator itself: the oracle's assembled matrix, and the matrix-free apply
+    A0 = amg.export(0, "A")
+    ref = po.Laplacian(1, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.bc_marker).assemble_csr()
+    assert abs(A0 - ref).max() < 1e-12 * abs(ref).max()
+    u = np.random.default_rng(0).standard_normal(lv.ndofs)
+    bc = lv.bc_marker.astype(bool)
+    u[bc] = 0.0
+    y = pm.Vector(layout)
+    op(_vec(pm, layout, u), y)
+    assert np.abs(A0 @ u - y.data_copy()).max() < 1e-12 * np.abs(y.data_copy()).max()
+    # Galerkin coarse operators, symmetric positive definite; Dirichlet rows stay out of the coarse space
+    A = A0
+    for l in range(L - 1):
+        P = amg.export(l, "P")
+        Ac = amg.export(l + 1, "A")
+        G = (P.T @ A @ P).tocsr()
+        assert abs(G - Ac).max() < 1e-12 * abs(Ac).max()
+        assert abs(Ac - Ac.T).max() < 1e-12 * abs(Ac).max()
+        assert Ac.shape[0] < 0.35 * A.shape[0]  # real coarsening
+        if l == 0:
+            assert abs(P[bc]).sum() == 0.0
+            # smoothed aggregation keeps the constant in the range of P away from the Dirichlet boundary:
+            # P c = (I - w D^-1 A) T c with T c = 1 on aggregated nodes, and A 1 = 0 on rows with no
+            # Dirichlet neighbour
+            sizes = np.asarray((P != 0).sum(axis=0)).ravel()
+            assert sizes.min() >= 1
+        A = Ac
+    w = np.linalg.eigvalsh(A.toarray())
+    assert w.min() > 0
+    info = amg.info()
+    opc = sum(i["nnz"] for i in info) / info[0]["nnz"]
+    assert opc < 2.5, opc  # operator complexity
+
+
+@pytest.mark.parametrize("n,k", [(12, 2), (16, 1), ((20, 9, 13), 3)])
+def test_cycle_equals_numpy_restatement(pm, n, k):
+    from oracle.amg_oracle import AmgCycle
+
+    part, lv, layout, op = _p1(pm, n)
+    amg = pm.AmgSolver(op, smoother_iterations=k)
+    L = amg.num_levels()
+    As = [amg.export(l, "A") for l in range(L)]
+    Ps = [amg.export(l, "P") for l in range(L - 1)]
+    ref = AmgCycle(As, Ps, [amg.level_info(l)["lambda_max"] for l in range(L)], k)
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal(lv.ndofs)
+    b[lv.bc_marker.astype(bool)] = 0.0
+    x = pm.Vector(layout)
+    x.set(7.0)  # the cycle starts from zero whatever x holds
+    amg.cycle(x, _vec(pm, layout, b))
+    want = ref.cycle(b)
+    assert np.abs(x.data_copy() - want).max() < 1e-11 * np.abs(want).max()
+    # the cycle is a symmetric operator (same polynomial before and after, P and P^T)
+    c = rng.standard_normal(lv.ndofs)
+    c[lv.bc_marker.astype(bool)] = 0.0
+    y = pm.Vector(layout)
+    amg.cycle(y, _vec(pm, layout, c))
+    assert abs(c @ x.data_copy() - b @ y.data_copy()) < 1e-10 * abs(c @ x.data_copy())
+    # Krylov mode against the same CG in numpy: same iteration count, same solution
+    amg2 = pm.AmgSolver(op, max_iter=60, rtol=1e-8, smoother_iterations=k)
+    xs = pm.Vector(layout)
+    its = amg2.solve(xs, _vec(pm, layout, b))
+    xr, its_ref = ref.pcg(lambda v: As[0] @ v, b, 1e-8, 60)
+    assert its == its_ref and its <= 14
+    assert np.abs(xs.data_copy() - xr).max() < 1e-8 * np.abs(xr).max()
+    assert np.abs(As[0] @ xs.data_copy() - b).max() < 1e-6 * np.abs(b).max()
+
+
+def test_contraction_and_mesh_independence(pm):
+    its, rho = [], []
+    for n in (12, 24, 36):
+        part, lv, layout, op = _p1(pm, n)
+        amg = pm.AmgSolver(op, max_iter=60, rtol=1e-8)
+        bcm = lv.bc_marker.astype(bool)
+        b = np.random.default_rng(n).standard_normal(lv.ndofs)
+        b[bcm] = 0.0
+        x = pm.Vector(layout)
+        its.append(amg.solve(x, _vec(pm, layout, b)))
+        # spectral radius of the error propagator I - M A of one cycle by the power method
+        e = pm.Vector(layout)
+        e.data.copy_(torch.from_numpy(b))
+        Ae, Me = pm.Vector(layout), pm.Vector(layout)
+        lam = 0.0
+        for _ in range(25):
+            op(e, Ae)
+            Ae.data[torch.from_numpy(bcm).cuda()] = 0.0
+            amg.cycle(Me, Ae)
+            pm.axpy(e, -1.0, Me, e)
+            lam = pm.norm(e)
+            pm.scale(e, 1.0 / lam)
+        rho.append(lam)
+    assert max(its) <= 14 and max(its) - min(its) <= 3, its  # h-independent
+    assert max(rho) < 0.45, rho
+
+
+def test_vcycle_with_amg_coarse_solver(pm):
+    """The p-multigrid cycle with the coarsest level solved by AMG (both modes): contraction per cycle,
+    against the same cycle with an exact coarse solve in the oracle."""
+    from oracle import pmg_oracle as po
+    import scipy.sparse.linalg as spla
+
+    n, orders, k = 12, (1, 2, 4), 3
+    h = pm.PoissonHierarchy(n, orders, kappa=2.0, cheb_its=k)
+    mesh, ops, sm, it, mg, b, eigs = po.build_hierarchy(n, orders, cheb_its=k)
+    for s, e in zip(sm, h.eig_ranges):
+        s.eig_range = e
+    lu = spla.splu(ops[0].assemble_csr().tocsc())
+
+    def exact(u0, b0):
+        u0[:] = lu.solve(b0)
+
+    mgo = po.MultigridPreconditioner(ops, sm, it, mesh.boundary_marker(orders[0]), coarse_solver=exact)
+    for mode in ("krylov", "stationary"):
+        amg = pm.AmgSolver(h.operators[0], max_iter=60, rtol=1e-10) if mode == "krylov" else \
+            pm.AmgSolver(h.operators[0], cycles=8)
+        h.mg.set_coarse_solver(amg)
+        x = h.new_vector()
+        x.set(0.0)
+        xo = np.zeros_like(b)
+        rn = []
+        for cyc in range(4):
+            rn.append(h.mg.apply(h.rhs[-1], x, verbose=True))
+            xo = mgo.apply(b, xo, compute_rnorm=True)
+            # an (almost) exact coarse solve on both sides: same iterates
+            assert np.abs(x.data_copy() - xo).max() < 1e-7 * np.abs(xo).max(), (mode, cyc)
+        assert all(rn[i + 1] < 0.2 * rn[i] for i in range(3)), (mode, rn)
+    # a coarse solver of the caller's own (any object with solve(x, b)) through the callback
+    calls = []
+
+    class Mine:
+        def __init__(self, inner):
+            self.inner = inner
+
+        def solve(self, xv, bv):
+            calls.append(1)
+            self.inner.solve(xv, bv)
+
+    h.mg.set_coarse_solver(Mine(pm.AmgSolver(h.operators[0], max_iter=60, rtol=1e-10)))
+    x2 = h.new_vector()
+    x2.set(0.0)
+    for cyc in range(4):
+        h.mg.apply(h.rhs[-1], x2)
+    assert len(calls) == 4
+    assert np.abs(x2.data_copy() - xo).max() < 1e-7 * np.abs(xo).max()
+    h.mg.set_coarse_solver(None)

@@ -102,3 +102,40 @@ def test_pmg_driver_coarse_cg(built):
     krylov = grab(r"Cycle \d+: residual norm = (\S+)", run("pmg_main", *args, "--coarse-cg"))
     assert len(plain) == len(krylov) == 4
     assert krylov[-1] < 0.1 * plain[-1]
+
+
+def test_pmg_driver_amg_and_native_communicator(built, tmp_path):
+    """--amg (the reference driver's flag, examples/pmg/main.cpp:331-335): CG + the library's AMG on the
+    degree-1 level; --amg-cycles: the same hierarchy as stationary cycles; --native-comm: the same run
+    with every scatter and reduction going through the RCCL communicator (one rank); --output."""
+    args = ("--n", 24, "--orders", "1,2,4", "--smoother-its", 3, "--cycles", 5)
+    plain = grab(r"Cycle \d+: residual norm = (\S+)", run("pmg_main", *args))
+    out = run("pmg_main", *args, "--amg", "--pcg", "--random-rhs")
+    amg = grab(r"Cycle \d+: residual norm = (\S+)", out)
+    assert "AMG coarse solver:" in out
+    assert all(amg[i + 1] < 0.2 * amg[i] for i in range(4)), amg  # contraction per cycle with a solved coarse level
+    assert amg[-1] < 1e-2 * plain[-1]
+    m = re.search(r"PCG with V-cycle preconditioner: (\d+) iterations, \|b - A x\| / \|b\| = (\S+)", out)
+    assert int(m.group(1)) <= 12 and float(m.group(2)) < 1e-6
+    stat = grab(r"Cycle \d+: residual norm = (\S+)", run("pmg_main", *args, "--amg-cycles", 2))
+    assert all(stat[i + 1] < 0.2 * stat[i] for i in range(4)), stat
+    # the RCCL communicator path gives the same numbers as the plain single-rank path
+    vtk = tmp_path / "u.vtk"
+    nat = run("pmg_main", *args, "--native-comm", "--id-file", tmp_path / "id", "--output", vtk)
+    got = grab(r"Cycle \d+: residual norm = (\S+)", nat)
+    assert len(got) == len(plain) and all(abs(a - b) < 1e-9 * b for a, b in zip(got, plain))
+    text = vtk.read_text().split("\n")
+    assert text[0].startswith("# vtk") and any(line.startswith("POINT_DATA") for line in text)
+
+
+def test_mat_free_driver_geometry_batching(built):
+    """--batch_size (examples/mat_free/main.cpp:34-50, src/laplacian.hpp:383-396): G recomputed batch by
+    batch in every apply -- same result, a fraction of the memory."""
+    full = run("mat_free_main", "--n", 12, "--degree", 3, "--nreps", 3)
+    bat = run("mat_free_main", "--n", 12, "--degree", 3, "--nreps", 3, "--batch_size", 200)
+    (y0,) = grab(r"Norm of y = (\S+)", full)
+    (y1,) = grab(r"Norm of y = (\S+)", bat)
+    assert y0 == y1  # the same arithmetic on the same tensor values
+    (m0,) = grab(r"Geometry tensor held: (\S+) MB", full)
+    (m1,) = grab(r"Geometry tensor held: (\S+) MB", bat)
+    assert m1 < 0.2 * m0 and "recomputed" in bat

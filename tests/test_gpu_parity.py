@@ -502,7 +502,7 @@ def test_vcycle_with_krylov_coarse_solver(pm):
         assert abs(rn - mgo.rnorm) < 1e-8 * mgo.rnorm
         rn_cg.append(rn)
     with pytest.raises(TypeError):
-        h.mg.set_coarse_solver(h.smoothers[0])
+        h.mg.set_coarse_solver(object())  # no solve(x, b)
     wrong = pm.CGSolver(h.layouts[1])
     with pytest.raises(RuntimeError, match="coarsest layout"):
         h.mg.set_coarse_solver(wrong)
@@ -631,5 +631,6 @@ def test_merged_and_coloured_launches_agree(pm, P, n):
     for name in ("coloured", "merged"):
         assert _relerr(got[name][0], ref) < 1e-12, name
         assert _relerr(got[name][2], ref) < 1e-12, name
-    # the coloured path uses no atomics: run-to-run identical
-    assert np.array_equal(got["coloured"][0], got["coloured"][2])
+    # no global atomics on the coloured path; inside a patch the cell sums meet in LDS in whatever
+    # order the wavefronts arrive, so two runs agree to rounding, not bit for bit
+    assert _relerr(got["coloured"][0], got["coloured"][2]) < 1e-14
