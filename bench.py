@@ -76,6 +76,12 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="skip the operator-apply sweep over degrees (N = 1 only)")
     ap.add_argument("--extras", action="store_true",
                     help="N > 1: also run the extra measurements (PCG, affine mode); by default only N = 1 does")
+    ap.add_argument("--exchange", choices=["native", "torch"], default="native",
+                    help="N > 1: halo + reductions on the library's own RCCL communicator (default) or through "
+                         "torch.distributed callbacks")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaled config-3 measurement")
+    ap.add_argument("--mesh-sweep", action="store_true",
+                    help="N = 1: PCG iteration counts at 32^3 / 64^3 / 96^3 with a random right-hand side")
     args = ap.parse_args()
 
     import numpy as np
@@ -105,9 +111,14 @@ def main():
     orders = tuple(int(p) for p in args.orders.split(","))
     dims = pm.default_proc_dims(world)
     n_global = tuple(args.n * d for d in dims) if args.scaling == "weak" else (args.n,) * 3
+    # one process per GPU: the library's RCCL communicator (grouped ncclSend/ncclRecv per halo, ncclAllReduce
+    # on device scalars), bootstrapped over the torch.distributed group the launcher gave us
+    comm = pm.RcclComm.from_torch(device=torch.device("cuda", local_rank)) if (world > 1 and args.exchange == "native") \
+        else None
 
     t0 = time.time()
-    H = pm.PoissonHierarchy(n_global, orders, kappa=2.0, cheb_its=args.cheb, proc_dims=dims, rank=rank, size=world)
+    H = pm.PoissonHierarchy(n_global, orders, kappa=2.0, cheb_its=args.cheb, proc_dims=dims, rank=rank, size=world,
+                            comm=comm)
     torch.cuda.synchronize()
     log(f"[rank {rank}] setup {time.time() - t0:.1f}s dims={dims} n_global={n_global} "
         f"local dofs={[lv.size_local for lv in H.levels]} ghosts={[lv.num_ghosts for lv in H.levels]} "
@@ -212,10 +223,78 @@ def main():
             "levels": list(reversed(orders)),
             "cheb_iterations": args.cheb,
             "partition": "x".join(str(d) for d in dims) + " bricks, 1 ghost-cell layer",
+            "exchange": ("library RCCL communicator (grouped send/recv, device all-reduce)" if comm is not None
+                         else "torch.distributed callbacks") if world > 1 else "none (single rank)",
             "stiffness_launches_per_cycle": {f"p{p}": c for p, c in zip(orders, counts)},
         },
         "roofline": roofline,
     }
+
+    def timed_cycles(Hx, bx, xx, k):
+        sync_all()
+        t = time.perf_counter()
+        for _ in range(k):
+            Hx.mg.apply(bx, xx)
+        sync_all()
+        t = time.perf_counter() - t
+        if world > 1:
+            tt = torch.tensor([t], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        return t
+
+    # ---- BASELINE config 3 (N > 1): the SAME 64^3 problem split over the N GPUs (strong scaling), next to the
+    # weak-scaled headline.  Not `value`.
+    if world > 1 and args.scaling == "weak" and not args.no_strong:
+        Hs = pm.PoissonHierarchy((args.n,) * 3, orders, kappa=2.0, cheb_its=args.cheb, proc_dims=dims, rank=rank,
+                                 size=world, comm=comm)
+        xs_ = Hs.new_vector()
+        xs_.set(0.0)
+        for _ in range(args.warmup):
+            Hs.mg.apply(Hs.rhs[-1], xs_)
+        ts = timed_cycles(Hs, Hs.rhs[-1], xs_, args.steps)
+        nd_s = Hs.part.global_ndofs(P)
+        out["strong_scaling"] = {"workload": f"BASELINE config 3: {args.n}^3 hexes in total over {world} GPUs",
+                                 "scaling": "strong", "value": nd_s * args.steps / ts, "unit": "DoF/s",
+                                 "ms_per_step": 1e3 * ts / args.steps, "fine_dofs_global": nd_s,
+                                 "local_dofs": [lv.size_local for lv in Hs.levels],
+                                 "ghosts": [lv.num_ghosts for lv in Hs.levels]}
+        del Hs, xs_
+
+    # ---- the cycle with its coarsest level SOLVED (the reference's --amg, examples/pmg/main.cpp:331-335): the
+    # library's AMG on the degree-1 level, as CG <= 60 iterations / rtol 1e-5 (the reference's shape) and as
+    # two stationary AMG cycles (no host synchronisation).  Reported next to the headline, which keeps the
+    # reference's default (coarsest level = its Chebyshev smoother, src/pmg.hpp:108-109).  Not `value`.
+    def _contraction(k=6):
+        xc_ = H.new_vector()
+        xc_.set(0.0)
+        rns = [H.mg.apply(b, xc_, verbose=True) for _ in range(k)]
+        return [rns[i + 1] / rns[i] for i in range(k - 1)], xc_
+
+    def _amg_coarse():
+        res = {"plain_cycle": {"coarse": "Chebyshev smoother (reference default)", "ms_per_step": ms_per_step,
+                               "residual_contraction_per_cycle": [round(c, 4) for c in _contraction()[0]]}}
+        t_setup = time.perf_counter()
+        modes = [("krylov", dict(max_iter=60, rtol=1e-5))]
+        if world == 1:
+            modes.append(("stationary_2_cycles", dict(cycles=2)))
+        for name, kw in modes:
+            amg = pm.AmgSolver(H.operators[0], **kw)
+            torch.cuda.synchronize()
+            setup_s = time.perf_counter() - t_setup
+            H.mg.set_coarse_solver(amg)
+            contr, xa = _contraction()
+            for _ in range(2):
+                H.mg.apply(b, xa)
+            ta = timed_cycles(H, b, xa, args.steps)
+            res[name] = {"ms_per_step": 1e3 * ta / args.steps, "value": fine_dofs_global * args.steps / ta,
+                         "unit": "DoF/s", "coarse_share_of_cycle": round(1.0 - ms_per_step / (1e3 * ta / args.steps), 4),
+                         "residual_contraction_per_cycle": [round(c, 4) for c in contr],
+                         "amg_levels": amg.info(), "setup_seconds": round(setup_s, 3)}
+            H.mg.set_coarse_solver(None)
+            t_setup = time.perf_counter()
+            del amg, xa
+        out["amg_coarse"] = res
 
     # ---- BASELINE config 2 as worded: CG preconditioned by the V-cycle, to rtol 1e-8 (extra, not `value`).
     # Two right-hand sides: a seeded random one (the honest measure of the preconditioner: every mode is
@@ -228,10 +307,14 @@ def main():
         g = np.random.default_rng(1000 + rank).standard_normal(lvf.ndofs)
         g[lvf.bc_marker.astype(bool)] = 0.0
         brand.data.copy_(torch.from_numpy(g))
-        for name, rhs in (("random_rhs", brand), ("manufactured_rhs", b)):
+        amg = pm.AmgSolver(H.operators[0], cycles=2) if world == 1 else pm.AmgSolver(H.operators[0])
+        for name, rhs in (("random_rhs", brand), ("manufactured_rhs", b), ("random_rhs_amg_coarse", brand)):
             cg = pm.CGSolver(H.layouts[-1])
             cg.set_max_iterations(200)
             cg.set_tolerance(1e-8)
+            if name.endswith("amg_coarse"):
+                H.mg.set_coarse_solver(amg)
+                cg.set_flexible(world > 1)  # Krylov coarse solve on several ranks: not a fixed linear operator
             xs = H.new_vector()
             xs.set(0.0)
             sync_all()
@@ -244,13 +327,52 @@ def main():
             pm.axpy(rr, -1.0, rr, rhs)
             res[name] = {"iterations": pcg_its, "seconds": t_pcg,
                          "true_relative_residual": pm.norm(rr) / pm.norm(rhs)}
+            H.mg.set_coarse_solver(None)
             del cg, xs, rr
         out["pcg"] = res
 
     extras = world == 1 or args.extras  # the scaling runs measure the headline only
     if extras:
+        with extra(out, "amg_coarse"):
+            _amg_coarse()
         with extra(out, "pcg"):
             _pcg()
+
+    # ---- h-independence of the outer PCG with a random right-hand side (extra, --mesh-sweep, N = 1) ----
+    def _mesh_sweep():
+        res = {}
+        for ns in (32, 64, 96):
+            Hm = H if ns == args.n else pm.PoissonHierarchy(ns, orders, kappa=2.0, cheb_its=args.cheb)
+            lvm = Hm.levels[-1]
+            g = np.random.default_rng(7).standard_normal(lvm.ndofs)
+            g[lvm.bc_marker.astype(bool)] = 0.0
+            bm = Hm.new_vector()
+            bm.data.copy_(torch.from_numpy(g))
+            entry = {}
+            for coarse in ("chebyshev", "amg_2_cycles"):
+                amg = pm.AmgSolver(Hm.operators[0], cycles=2) if coarse != "chebyshev" else None
+                Hm.mg.set_coarse_solver(amg)
+                cg = pm.CGSolver(Hm.layouts[-1])
+                cg.set_max_iterations(200)
+                cg.set_tolerance(1e-8)
+                xm = Hm.new_vector()
+                xm.set(0.0)
+                torch.cuda.synchronize()
+                tm = time.perf_counter()
+                its = cg.solve(Hm.operators[-1], xm, bm, preconditioner=Hm.mg)
+                torch.cuda.synchronize()
+                entry[coarse] = {"iterations": its, "seconds": round(time.perf_counter() - tm, 4)}
+                Hm.mg.set_coarse_solver(None)
+                del cg, xm, amg
+            res[f"{ns}^3"] = entry
+            if Hm is not H:
+                del Hm
+            torch.cuda.empty_cache()
+        out["pcg_mesh_sweep"] = {"rtol": 1e-8, "rhs": "standard normal, seed 7", **res}
+
+    if world == 1 and args.mesh_sweep:
+        with extra(out, "pcg_mesh_sweep"):
+            _mesh_sweep()
 
     # ---- extra, reported separately and never mixed into `value`/`roofline`: the same V-cycle with the
     # affine-cell geometry mode (one constant tensor per cell instead of the stored G stream; byte model
@@ -285,17 +407,27 @@ def main():
             kms = op.time_kernel(u, y, args.kernel_reps)
             N_, U_ = (P + 1) ** 3, P**3
             cellg = (4 * N_ + 56 + 17 * U_) * ncells_launch
-            # same iterates as the stored-G cycle?  (x after warmup+steps cycles from 0 in both modes)
+            # same iterates as the stored-G cycle?  (three cycles from x = 0 in either mode)
+            xa.set(0.0)
+            for _ in range(3):
+                H.mg.apply(b, xa)
+            for o in H.operators:
+                o.set_geometry_mode("stored")
+            xs3 = H.new_vector()
+            xs3.set(0.0)
+            for _ in range(3):
+                H.mg.apply(b, xs3)
+            nl = H.levels[-1].size_local
             out["affine_geometry"] = {
                 "value": fine_dofs_global * args.steps / ta, "unit": "DoF/s", "ms_per_step": 1e3 * ta / args.steps,
                 "note": "same V-cycle, geometry mode 'affine' (not the reference's data structure); not `value`",
                 "roofline": {"bound": "hbm", "byte_model": "cellG: 4N + 56 + 17U bytes per cell",
                              "achieved": round(cellg / (kms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(cellg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(kms, 5)},
-                "max_rel_diff_vs_stored": float((xa.data[: H.levels[-1].size_local]
-                                                 - x.data[: H.levels[-1].size_local]).abs().max()
-                                                / x.data[: H.levels[-1].size_local].abs().max()),
+                "max_rel_diff_vs_stored_after_3_cycles": float((xa.data[:nl] - xs3.data[:nl]).abs().max()
+                                                               / xs3.data[:nl].abs().max()),
             }
+            del xs3
             del xa
 
     if extras:

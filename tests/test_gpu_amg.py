@@ -176,8 +176,10 @@ def test_vcycle_with_amg_coarse_solver(pm):
         for cyc in range(4):
             rn.append(h.mg.apply(h.rhs[-1], x, verbose=True))
             xo = mgo.apply(b, xo, compute_rnorm=True)
-            # an (almost) exact coarse solve on both sides: same iterates
-            assert np.abs(x.data_copy() - xo).max() < 1e-7 * np.abs(xo).max(), (mode, cyc)
+            # an (almost) exact coarse solve on both sides: same iterates (eight stationary cycles leave a
+            # coarse error of ~1e-5, the Krylov solve to 1e-10 next to nothing)
+            tol = 1e-7 if mode == "krylov" else 1e-5
+            assert np.abs(x.data_copy() - xo).max() < tol * np.abs(xo).max(), (mode, cyc)
         assert all(rn[i + 1] < 0.2 * rn[i] for i in range(3)), (mode, rn)
     # a coarse solver of the caller's own (any object with solve(x, b)) through the callback
     calls = []

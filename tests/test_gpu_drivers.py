@@ -115,7 +115,7 @@ def test_pmg_driver_amg_and_native_communicator(built, tmp_path):
     assert "AMG coarse solver:" in out
     assert all(amg[i + 1] < 0.2 * amg[i] for i in range(4)), amg  # contraction per cycle with a solved coarse level
     assert amg[-1] < 1e-2 * plain[-1]
-    m = re.search(r"PCG with V-cycle preconditioner: (\d+) iterations, \|b - A x\| / \|b\| = (\S+)", out)
+    m = re.search(r"PCG with V-cycle preconditioner: (\d+) iterations, \|b - A x\| / \|b\| = ([0-9.e+-]+)", out)
     assert int(m.group(1)) <= 12 and float(m.group(2)) < 1e-6
     stat = grab(r"Cycle \d+: residual norm = (\S+)", run("pmg_main", *args, "--amg-cycles", 2))
     assert all(stat[i + 1] < 0.2 * stat[i] for i in range(4)), stat
@@ -135,7 +135,7 @@ def test_mat_free_driver_geometry_batching(built):
     bat = run("mat_free_main", "--n", 12, "--degree", 3, "--nreps", 3, "--batch_size", 200)
     (y0,) = grab(r"Norm of y = (\S+)", full)
     (y1,) = grab(r"Norm of y = (\S+)", bat)
-    assert y0 == y1  # the same arithmetic on the same tensor values
+    assert abs(y0 - y1) < 1e-13 * y0  # the same tensor values (sums meet in LDS in arrival order)
     (m0,) = grab(r"Geometry tensor held: (\S+) MB", full)
     (m1,) = grab(r"Geometry tensor held: (\S+) MB", bat)
     assert m1 < 0.2 * m0 and "recomputed" in bat
