@@ -358,6 +358,9 @@ __device__ __forceinline__ double2 gload(const double2* p)
     return *p;
 }
 
+#ifndef PMG_ABL
+#define PMG_ABL 0 // tuning builds (tools/build_ablation.sh): 1 linear write-back, 2 no write-back, 4 linear gather
+#endif
 #ifndef PMG_WPS_HI
 #define PMG_WPS_HI 1
 #endif
@@ -419,6 +422,12 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
     {
       const uint32_t dof = m[k] & PD_MASK;
       const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+      if (PMG_ABL & 4)
+      {
+        xv[k] = x[(size_t)p * MAXM + (t + k * THREADS < M ? t + k * THREADS : M - 1)];
+        yv[k] = x[(size_t)p * MAXM + (t + k * THREADS < M ? t + k * THREADS : M - 1) + (acc ? 1 : 0)];
+        continue;
+      }
       xv[k] = x[dof];
       const double* ya = acc ? (const double*)(y + dof) : (x + dof);
       yv[k] = *ya;
@@ -643,6 +652,17 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
     {
       const uint32_t mk = pdofs[off + i];
       const uint32_t dof = mk & PD_MASK;
+      if (PMG_ABL & 2)
+      {
+        if (sy[i] == 1.2345e300)
+          y[dof] = 0.0;
+        continue;
+      }
+      if (PMG_ABL & 1)
+      {
+        __builtin_nontemporal_store(sy[i], &y[(size_t)p * MAXM + i]);
+        continue;
+      }
       if (mk & PD_BC)
       {
         if (!(mk & PD_ACC))

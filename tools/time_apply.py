@@ -8,10 +8,10 @@ P, n = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 part = pm.BoxPartition(n); lv = part.level(P); layout = pm.make_layout(lv)
 op = pm.MatFreeLaplacian(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells, lv.bc_marker, layout)
-x = pm.Vector(layout)
-x.data.copy_(torch.randn(lv.ndofs, dtype=torch.float64, device="cuda"))
 class V: pass
-v = V(); v.data = torch.zeros(part.ncells * (P + 1) ** 3 + 16, dtype=torch.float64, device="cuda")  # room for the ABL=2 store
+big = part.ncells * (P + 1) ** 3 * 2 + 4096  # room for the linear gather / write-back ablations
+x = V(); x.data = torch.randn(big, dtype=torch.float64, device="cuda")
+v = V(); v.data = torch.zeros(big, dtype=torch.float64, device="cuda")
 op.time_kernel(x, v, 3)
 ms = op.time_kernel(x, v, reps) * op.launches_per_apply()
 N, U = (P + 1) ** 3, P ** 3
