@@ -378,6 +378,16 @@ int pmg_multigrid_set_coarse_amg(pmg_multigrid mg, pmg_amg amg);
  * host synchronisation. */
 int pmg_multigrid_apply(pmg_multigrid mg, const double* rhs, double* y, double* rnorm,
                         pmg_stream stream);
+/* hipGraph replay of the cycle.  With enable != 0, pmg_multigrid_apply (and the V-cycle preconditioner
+ * inside pmg_cg_solve) captures the cycle's ~120 launches into a graph the first time it sees a
+ * (rhs, y) pair and replays it afterwards with one hipGraphLaunch on the caller's stream: same
+ * kernels, same order, same results.  Captured only when nothing in the cycle needs the host: a
+ * single rank, no Krylov / callback coarse solver, no in-situ profiling; otherwise the call runs
+ * eagerly as before.  A change of a smoother's iteration count or bound, of a geometry mode or of the
+ * coarse solver is noticed (new graph); calling this function again drops the cached graphs (do that
+ * after replacing an operator's diagonal or any caller-owned array in place). */
+int pmg_multigrid_set_graph(pmg_multigrid mg, int enable);
+long long pmg_multigrid_graph_replays(pmg_multigrid mg);
 /* Number of stiffness-kernel launches issued by the last pmg_multigrid_apply,
  * per level (coarse -> fine); for the byte accounting in bench.py. */
 int pmg_multigrid_apply_counts(pmg_multigrid mg, int* counts, int capacity);

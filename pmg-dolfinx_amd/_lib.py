@@ -133,10 +133,12 @@ _SIGS = {
     "pmg_laplacian_geometry_bytes": (C.c_longlong, [vp]),
     "pmg_multigrid_apply": (C.c_int, [vp, vp, vp, c_dp, vp]),
     "pmg_multigrid_apply_counts": (C.c_int, [vp, C.POINTER(C.c_int), C.c_int]),
+    "pmg_multigrid_set_graph": (C.c_int, [vp, C.c_int]),
+    "pmg_multigrid_graph_replays": (C.c_longlong, [vp]),
 }
 
 # functions whose int return value is a count, not a status
-_COUNT_FUNCS = {"pmg_amg_num_levels", "pmg_laplacian_geometry_bytes", "pmg_comm_rank", "pmg_comm_size", "pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
+_COUNT_FUNCS = {"pmg_multigrid_graph_replays", "pmg_amg_num_levels", "pmg_laplacian_geometry_bytes", "pmg_comm_rank", "pmg_comm_size", "pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
                 "pmg_laplacian_degree", "pmg_laplacian_launches_per_apply", "pmg_laplacian_is_affine"}
 
 _lib = None

@@ -536,6 +536,12 @@ namespace pmg
 {
 pmg_layout amg_layout(pmg_amg amg) { return amg->layout; }
 
+// stationary cycles are stream-ordered and capturable; the Krylov mode synchronises the host
+long long amg_capture_state(pmg_amg amg)
+{
+  return amg->cycles > 0 ? ((long long)amg->cycles << 16) ^ amg->smoother_its : -1;
+}
+
 // x = (approximately) A^-1 b on the coarsest p-level, x zero on entry is not assumed
 int amg_solve(pmg_amg amg, double* x, const double* b, hipStream_t s)
 {

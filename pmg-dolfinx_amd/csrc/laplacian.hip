@@ -917,6 +917,14 @@ struct LaplacianInputs
 };
 LaplacianInputs laplacian_inputs(pmg_laplacian op) { return {op->P, op->ncells, op->dofmap, op->bc, op->kappa}; }
 
+// what a captured graph of launches of this operator depends on; -1 = not capturable right now
+long long laplacian_capture_state(pmg_laplacian op)
+{
+  if (op->profiling)
+    return -1;
+  return ((long long)op->geometry_mode << 40) ^ ((long long)op->batch_patches << 8) ^ (long long)(op->have_diag ? 1 : 0);
+}
+
 PatchView laplacian_patches(pmg_laplacian op)
 {
   PatchView v;

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 using namespace pmg;
 
@@ -29,6 +30,8 @@ int interp_prolong_add(pmg_interpolator ip, double* coarse, double* fine, hipStr
 bool interp_is_patched(pmg_interpolator ip);
 int amg_solve(pmg_amg amg, double* x, const double* b, hipStream_t s);
 pmg_layout amg_layout(pmg_amg amg);
+long long amg_capture_state(pmg_amg amg);
+long long laplacian_capture_state(pmg_laplacian op);
 void launch_cheb_first(int n, double* x, double* r, double* z, const double* q, const double* dinv,
                        double c1, double c2, hipStream_t s);
 } // namespace pmg
@@ -68,6 +71,21 @@ struct pmg_multigrid_s
   pmg_coarse_solve_fn coarse_fn = nullptr;
   void* coarse_user = nullptr;
   pmg_amg coarse_amg = nullptr;
+  // hipGraph replay of the cycle (pmg_multigrid_set_graph): one executable graph per
+  // (rhs, y, zero-guess, configuration) seen
+  struct GraphEntry
+  {
+    const double* rhs;
+    double* y;
+    bool y_zero;
+    uint64_t config;
+    hipGraphExec_t exec;
+    std::vector<int> counts;
+  };
+  bool graph_enabled = false;
+  std::vector<GraphEntry> graphs;
+  hipStream_t capture_stream = nullptr;
+  long long graph_replays = 0;
 };
 
 namespace pmg
@@ -119,6 +137,8 @@ int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n,
 
 namespace
 {
+int mg_apply_graph(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStream_t s, bool* done);
+
 int alloc_vec(pmg_layout l, double** p)
 {
   size_t n = l->total() ? l->total() : 1;
@@ -411,7 +431,13 @@ extern "C" int pmg_cg_solve(pmg_cg cg, pmg_laplacian A, double* x, const double*
   hipStream_t s = S(stream);
   const ApplyFn apply = [A, s](double* in, double* out) { return laplacian_apply(A, in, out, s); };
   // the V-cycle from a zero initial guess: folded into the smoothers' x_zero path, no memset of z
-  const PrecondFn vcycle = [precond, s](double* z, const double* r) { return mg_apply(precond, r, z, true, s); };
+  const PrecondFn vcycle = [precond, s](double* z, const double* r) -> int
+  {
+    bool done = false;
+    if (precond->graph_enabled)
+      PMG_TRY(mg_apply_graph(precond, r, z, true, s, &done));
+    return done ? PMG_OK : mg_apply(precond, r, z, true, s);
+  };
   return cg_iterate(cg, apply, laplacian_diag_inv(A), precond ? &vcycle : nullptr, cg->flexible, x, b, iterations, s);
 }
 
@@ -538,6 +564,10 @@ extern "C" int pmg_multigrid_destroy(pmg_multigrid mg)
     (void)hipFree(mg->u[i]);
     (void)hipFree(mg->b[i]);
   }
+  for (auto& g : mg->graphs)
+    (void)hipGraphExecDestroy(g.exec);
+  if (mg->capture_stream)
+    (void)hipStreamDestroy(mg->capture_stream);
   delete mg;
   return PMG_OK;
 }
@@ -574,12 +604,116 @@ extern "C" int pmg_multigrid_set_interpolators(pmg_multigrid mg, const pmg_inter
   return PMG_OK;
 }
 
+namespace
+{
+void drop_graphs(pmg_multigrid mg)
+{
+  for (auto& g : mg->graphs)
+    (void)hipGraphExecDestroy(g.exec);
+  mg->graphs.clear();
+}
+
+// What a captured cycle depends on besides its two vectors; -1: this configuration cannot be
+// captured (a host synchronisation or a host callback inside the cycle, in-situ timing events)
+long long capture_config(pmg_multigrid mg)
+{
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+  for (int i = 0; i < mg->L; ++i)
+  {
+    pmg_layout l = mg->layouts[i];
+    if (l->comm || l->exchange) // halo: the callbacks cannot be captured; RCCL capture is untested here
+      return -1;
+    const long long st = laplacian_capture_state(mg->ops[i]);
+    if (st < 0)
+      return -1;
+    mix((uint64_t)st);
+    mix((uint64_t)mg->smoothers[i]->max_iter);
+    uint64_t bits;
+    static_assert(sizeof(bits) == sizeof(double), "");
+    memcpy(&bits, &mg->smoothers[i]->eig_max, sizeof(bits));
+    mix(bits);
+  }
+  if (mg->coarse || mg->coarse_fn) // Krylov coarse solve / caller's solver: host in the loop
+    return -1;
+  if (mg->coarse_amg)
+  {
+    const long long st = amg_capture_state(mg->coarse_amg);
+    if (st < 0)
+      return -1;
+    mix((uint64_t)st);
+  }
+  return (long long)(h >> 1);
+}
+
+// mg_apply through a graph: captured on the library's own stream the first time a
+// (vectors, configuration) combination is seen, replayed on the caller's stream afterwards
+int mg_apply_graph(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStream_t s, bool* done)
+{
+  *done = false;
+  if ((int)mg->ops.size() != mg->L || (int)mg->smoothers.size() != mg->L)
+    return PMG_OK; // mg_apply reports it
+  const long long cfg = capture_config(mg);
+  if (cfg < 0)
+    return PMG_OK;
+  for (auto& g : mg->graphs)
+    if (g.rhs == rhs && g.y == y && g.y_zero == y_zero && g.config == (uint64_t)cfg)
+    {
+      PMG_HIP(hipGraphLaunch(g.exec, s));
+      mg->counts = g.counts;
+      mg->graph_replays++;
+      *done = true;
+      return PMG_OK;
+    }
+  if (!mg->capture_stream)
+    PMG_HIP(hipStreamCreateWithFlags(&mg->capture_stream, hipStreamNonBlocking));
+  PMG_HIP(hipStreamBeginCapture(mg->capture_stream, hipStreamCaptureModeRelaxed));
+  const int rc = mg_apply(mg, rhs, y, y_zero, mg->capture_stream);
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(mg->capture_stream, &graph);
+  if (rc != PMG_OK)
+  {
+    if (graph)
+      (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  if (e != hipSuccess || !graph)
+    return fail(PMG_ERR_HIP, "capturing the V-cycle failed: %s", hipGetErrorString(e));
+  pmg_multigrid_s::GraphEntry g{rhs, y, y_zero, (uint64_t)cfg, nullptr, mg->counts};
+  const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess)
+    return fail(PMG_ERR_HIP, "instantiating the V-cycle graph failed: %s", hipGetErrorString(ei));
+  if (mg->graphs.size() >= 16) // callers that cycle through many vectors: keep the cache small
+    drop_graphs(mg);
+  mg->graphs.push_back(g);
+  PMG_HIP(hipGraphLaunch(g.exec, s));
+  mg->graph_replays++;
+  *done = true;
+  return PMG_OK;
+}
+} // namespace
+
+extern "C" int pmg_multigrid_set_graph(pmg_multigrid mg, int enable)
+{
+  PMG_REQUIRE(mg, "pmg_multigrid_set_graph: NULL argument");
+  drop_graphs(mg);
+  mg->graph_enabled = enable != 0;
+  return PMG_OK;
+}
+
+extern "C" long long pmg_multigrid_graph_replays(pmg_multigrid mg) { return mg ? mg->graph_replays : -1; }
+
 extern "C" int pmg_multigrid_apply(pmg_multigrid mg, const double* rhs, double* y, double* rnorm,
                                    pmg_stream stream)
 {
   PMG_REQUIRE(mg && rhs && y, "pmg_multigrid_apply: NULL argument");
   hipStream_t s = S(stream);
-  PMG_TRY(mg_apply(mg, rhs, y, false, s));
+  bool done = false;
+  if (mg->graph_enabled)
+    PMG_TRY(mg_apply_graph(mg, rhs, y, false, s, &done));
+  if (!done)
+    PMG_TRY(mg_apply(mg, rhs, y, false, s));
   if (rnorm) // src/pmg.hpp:141-150
   {
     const int L = mg->L;

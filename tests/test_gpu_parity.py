@@ -289,6 +289,58 @@ def test_config2_full_size_vcycle_against_c_oracle(pm):
         assert _relerr(x.data_copy(), xo) < 1e-10, cyc
 
 
+def test_vcycle_graph_replay(pm):
+    """pmg_multigrid_set_graph: the cycle replayed as a hipGraph gives the eager cycle's iterates (same
+    kernels in the same order), also as the preconditioner of CG and with the stationary AMG coarse
+    solver; configurations that need the host inside the cycle fall back to eager launches."""
+    h = pm.PoissonHierarchy(8, (1, 2, 4), kappa=2.0, cheb_its=3, warp=warp)
+    b = h.rhs[-1]
+
+    def cycles(k):
+        x = h.new_vector()
+        x.set(0.0)
+        for _ in range(k):
+            rn = h.mg.apply(b, x, verbose=True)
+        return x.data_copy(), rn
+
+    for coarse in (None, "amg"):
+        amg = pm.AmgSolver(h.operators[0], cycles=1) if coarse else None
+        h.mg.set_coarse_solver(amg)
+        h.mg.set_graph(False)
+        eager, rn_e = cycles(3)
+        h.mg.set_graph(True)
+        n0 = h.mg.graph_replays()
+        graph, rn_g = cycles(3)
+        assert h.mg.graph_replays() == n0 + 3
+        assert _relerr(graph, eager) < 1e-13 and abs(rn_g - rn_e) < 1e-12 * rn_e
+        # a changed smoother degree is a different graph, not a stale replay
+        h.smoothers[-1].set_max_iterations(2)
+        h.mg.set_graph(False)
+        eager2, _ = cycles(2)
+        h.mg.set_graph(True)
+        graph2, _ = cycles(2)
+        assert _relerr(graph2, eager2) < 1e-13 and _relerr(graph2, eager[: graph2.size]) > 1e-6
+        h.smoothers[-1].set_max_iterations(3)
+        # as the preconditioner of CG
+        sols = []
+        for flag in (False, True):
+            h.mg.set_graph(flag)
+            cg = pm.CGSolver(h.layouts[-1])
+            cg.set_max_iterations(30)
+            cg.set_tolerance(1e-10)
+            xs = h.new_vector()
+            xs.set(0.0)
+            sols.append((cg.solve(h.operators[-1], xs, b, preconditioner=h.mg), xs.data_copy()))
+        assert sols[0][0] == sols[1][0] and _relerr(sols[1][1], sols[0][1]) < 1e-11
+    # a Krylov coarse solver synchronises the host: eager, no replay
+    h.mg.set_coarse_solver(pm.AmgSolver(h.operators[0]))
+    n0 = h.mg.graph_replays()
+    cycles(1)
+    assert h.mg.graph_replays() == n0
+    h.mg.set_coarse_solver(None)
+    h.mg.set_graph(False)
+
+
 def test_errors(pm):
     part = pm.BoxPartition(2)
     lv = part.level(1)
