@@ -537,11 +537,7 @@ TransferArgs make_args(pmg_interpolator ip, int first)
   A.K = ip->fv.K;
   A.max_mf = ip->fv.max_m;
   A.max_mc = ip->cmax_m;
-#ifdef PMG_NO_NT
-  A.nt = 0;
-#else
   A.nt = ip->lf->total() >= (4 << 20) ? 1 : 0; // same rule as the smoother kernels (vector.hip)
-#endif
   A.poff = ip->fv.poff;
   A.lmap_id = ip->fv.lmap_id;
   A.pncell = ip->fv.pncell;

@@ -106,13 +106,9 @@ struct Shape
   static constexpr int CW = NQ2 <= 64 ? 64 / NQ2 : 1;
   static constexpr int WPC = (NQ2 + 63) / 64;      // waves that share one cell (2 at P = 8)
   static constexpr int ITEMS = (K + CW - 1) / CW;  // wave-items per full patch
-#ifdef PMG_NW
-  static constexpr int NWMAX = PMG_NW; // tuning build
-#else
-  // measured (profiles/kernel_roofline): 4 waves and more workgroups per CU for the
-  // register-heavy degrees and P = 3 (518 -> 496 us), 8 waves otherwise
+  // measured (profiles/kernel_roofline_r01.md, profiles/kernel_tuning_r02.md): 4 waves and more
+  // workgroups per CU for the register-heavy degrees and P = 3, 8 waves otherwise
   static constexpr int NWMAX = (P == 3 || P == 5 || P == 6 || P == 8) ? 4 : 8;
-#endif
   static constexpr int NG = ITEMS < NWMAX / WPC ? ITEMS : NWMAX / WPC; // items in flight per workgroup
   static constexpr int NW = NG * WPC;                                  // waves per workgroup
   static constexpr int WTHREADS = NW * 64;
@@ -158,17 +154,14 @@ __device__ inline void jacobian(const double* __restrict__ xgeom,
 
 // Layout of the stored geometry tensor G (double2 pairs (G00,G01)(G02,G11)(G12,G22)).
 //   default: [slot][layer c][pair][a*nd+b]
-//   flat (degrees in PMG_GFLAT_MASK): [patch][item][layer c][pair][cell of the item][a*nd+b],
+//   flat (P = 2, gflat()): [patch][item][layer c][pair][cell of the item][a*nd+b],
 //     every (item, layer) block padded to whole 128-byte lines -- a wavefront then reads its item's
 //     layer as NJ full-width loads of 64 consecutive double2 (whole lines, none shared between two
 //     load instructions) and hands the values to the lanes that use them through LDS.  Pays where
 //     the per-cell planes are short and misaligned: P = 2 (seven 144-byte pieces per load
 //     instruction otherwise), 765 -> 674 us at 128^3; slower at P = 1, 3, 4 (1485 -> 1524, 513 -> 549,
 //     458 -> 480 us), so only P = 2 uses it.
-#ifndef PMG_GFLAT_MASK
-#define PMG_GFLAT_MASK (1 << 2) // bit P
-#endif
-__host__ __device__ constexpr bool gflat(int nd) { return nd * nd <= 64 && ((PMG_GFLAT_MASK >> (nd - 1)) & 1); }
+__host__ __device__ constexpr bool gflat(int nd) { return nd == 3; } // P = 2 only
 __host__ __device__ constexpr int gcw(int nd) { return nd * nd <= 64 ? 64 / (nd * nd) : 1; }
 __host__ __device__ constexpr int gls(int nd) { return ((3 * gcw(nd) * nd * nd + 7) / 8) * 8; } // layer stride
 __host__ __device__ constexpr long long gpatch(int nd, int K)
@@ -307,9 +300,6 @@ __device__ __forceinline__ void lds_barrier()
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-#ifdef PMG_STAMPS
-__device__ unsigned long long* pmg_stamp_buf = nullptr;
-#endif
 
 // ---- the hot kernel, column form --------------------------------------
 //
@@ -337,14 +327,10 @@ __device__ __forceinline__ void wave_fence()
 // the dof lists and the shared tables from L2 / MALL, and the write-back stores of y are
 // non-temporal as well.  Measured at P = 4, 64^3: 505 -> 475 us with nt stores, -> 430 us
 // with nt G loads on top; the sc0 / sc1 bits make no difference; nt on the x / y gathers
-// or on the dof lists is slower.  -DPMG_NO_NT restores the default policy (tuning build).
+// or on the dof lists is slower.
 // At P = 1 (8 quadrature points per cell, every dof shared by 8 cells) the default
 // policy is faster (1610 vs 1750 us at 256^3), so the hint starts at P = 2.
-#ifdef PMG_NO_NT
-#define PMG_NT_FROM 99
-#else
-#define PMG_NT_FROM 2
-#endif
+constexpr int NT_FROM = 2;
 typedef double gvec2 __attribute__((ext_vector_type(2)));
 template <bool NT>
 __device__ __forceinline__ double2 gload(const double2* p)
@@ -358,17 +344,12 @@ __device__ __forceinline__ double2 gload(const double2* p)
     return *p;
 }
 
-#ifndef PMG_ABL
-#define PMG_ABL 0 // tuning builds (tools/build_ablation.sh): 1 linear write-back, 2 no write-back, 4 linear gather
-#endif
-#ifndef PMG_WPS_HI
-#define PMG_WPS_HI 1
-#endif
-#ifndef PMG_WPS
-#define PMG_WPS (P <= 4 ? (2 * Shape<P>::NW + 3) / 4 : PMG_WPS_HI)
-#endif
+// minimum waves per SIMD the register allocation has to leave room for: two workgroups per CU up to
+// P = 4; the register-heavy degrees take what they need (profiles/kernel_resources_r02.md)
+template <int P>
+constexpr int min_waves_per_simd() { return P <= 4 ? (2 * Shape<P>::NW + 3) / 4 : 1; }
 template <int P, bool AFF>
-__global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
+__global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     stiffness_column_kernel(const double* __restrict__ x, double* __restrict__ y,
                             const double2* __restrict__ G, const double* __restrict__ Gaff,
                             const double* __restrict__ W1, const int32_t* __restrict__ poff,
@@ -382,7 +363,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
   constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, NQ2 = Sh::NQ2, CW = Sh::CW, NG = Sh::NG, WPC = Sh::WPC;
   constexpr int MAXM = Sh::MAXM, THREADS = Sh::WTHREADS, ITER = Sh::WITER;
   constexpr int WL = CW * NQ2; // columns of one item (a wave, or WPC waves sharing a cell)
-  constexpr bool NT = P >= PMG_NT_FROM; // streaming cache policy for G and the y write-back
+  constexpr bool NT = P >= NT_FROM; // streaming cache policy for G and the y write-back
   __shared__ double sD[ND * ND];
   __shared__ double skap[K];
   __shared__ double sx[MAXM];
@@ -397,9 +378,6 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
 
   const int p = first + blockIdx.x;
   const int t = threadIdx.x;
-#ifdef PMG_STAMPS // diagnostic build only: wall-clock stamps (100 MHz) of the phases of every workgroup
-  unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
-#endif
   const int off = poff[p];
   const int M = poff[p + 1] - off; // 1 <= M <= MAXM
   const int table = lmap_id[p];
@@ -422,12 +400,6 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
     {
       const uint32_t dof = m[k] & PD_MASK;
       const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
-      if (PMG_ABL & 4)
-      {
-        xv[k] = x[(size_t)p * MAXM + (t + k * THREADS < M ? t + k * THREADS : M - 1)];
-        yv[k] = x[(size_t)p * MAXM + (t + k * THREADS < M ? t + k * THREADS : M - 1) + (acc ? 1 : 0)];
-        continue;
-      }
       xv[k] = x[dof];
       const double* ya = acc ? (const double*)(y + dof) : (x + dof);
       yv[k] = *ya;
@@ -450,9 +422,6 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
       skap[i] = (i == t) ? kapk : kappa[pcell[(size_t)p * K + i] >= 0 ? pcell[(size_t)p * K + i] : 0];
   }
   lds_barrier();
-#ifdef PMG_STAMPS
-  unsigned long long st1 = __builtin_amdgcn_s_memrealtime();
-#endif
 
   // ---- cell loop: each wave on its own
   // (nd^2 > 64, i.e. P = 8: WPC waves share a cell, the slices are exchanged between
@@ -464,34 +433,18 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
   const int cw = lw / NQ2;          // cell of this lane inside the wave item
   const int ab = lw - cw * NQ2;     // column: a = x index, b = y index
   const int a = ab / ND, b = ab - a * ND;
-#ifndef PMG_GDEPTH
-#define PMG_GDEPTH 1
-#endif
-  // The lane's rows / columns of the 1-D table: in registers (4 nd doubles) for the
-  // low degrees; from degree DLDS_FROM on they are re-read from LDS in every layer, which
-  // frees 8 nd VGPRs for one more wave per SIMD (zl is an opaque zero that keeps the
-  // compiler from hoisting the reads back into registers).
-#ifndef PMG_DLDS_FROM
-#define PMG_DLDS_FROM 9
-#endif
-  constexpr bool DLDS = P >= PMG_DLDS_FROM;
+  // The lane's rows / columns of the 1-D table, in registers (4 nd doubles; re-reading them from LDS
+  // in every layer frees the registers for one more wave per SIMD but is 15 % slower at every degree,
+  // profiles/kernel_tuning_r02.md)
   double Da[ND], Db[ND], DTa[ND], DTb[ND]; // D[a][.], D[b][.], D[.][a], D[.][b]
-  if constexpr (!DLDS)
-  {
 #pragma unroll
-    for (int mm = 0; mm < ND; ++mm)
-    {
-      Da[mm] = sD[a * ND + mm];
-      Db[mm] = sD[b * ND + mm];
-      DTa[mm] = sD[mm * ND + a];
-      DTb[mm] = sD[mm * ND + b];
-    }
+  for (int mm = 0; mm < ND; ++mm)
+  {
+    Da[mm] = sD[a * ND + mm];
+    Db[mm] = sD[b * ND + mm];
+    DTa[mm] = sD[mm * ND + a];
+    DTb[mm] = sD[mm * ND + b];
   }
-  int zl = 0;
-#define DA(m) (DLDS ? sD[zl + a * ND + (m)] : Da[m])
-#define DB(m) (DLDS ? sD[zl + b * ND + (m)] : Db[m])
-#define DTA(m) (DLDS ? sD[zl + (m) * ND + a] : DTa[m])
-#define DTB(m) (DLDS ? sD[zl + (m) * ND + b] : DTb[m])
   const double wab = AFF ? W1[a] * W1[b] : 0.0; // 1-D GLL weights of the lane's column
   double* q_s = sq + wave * WL + cw * NQ2;  // this cell's slices
   double* gr_s = sgr + wave * WL + cw * NQ2;
@@ -516,7 +469,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
       l[k] = lm[k * NQ2];
     // storedG: G layers 0 .. GD-1 in flight (empty slots hold zeros).
     // affine cells (AFF): G_q = w_a w_b w_c * Gc with one constant tensor Gc per cell.
-    constexpr int GD = ND < PMG_GDEPTH ? ND : PMG_GDEPTH;
+    constexpr int GD = 1; // G layers in flight per wave (deeper costs registers, i.e. resident waves: no gain)
     double2 gq[AFF ? 1 : GD][3];
     double2 gfl[FLAT ? NJ : 1]; // flat layout: the next layer as loaded
     // (only used when FLAT; the item index is wave-uniform: a scalar base plus 32-bit lane offsets)
@@ -600,16 +553,14 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
           gq[k % GD][2] = gload<NT>(Gs + (k + GD) * 3 * NQ2 + 2 * NQ2);
         }
       }
-      if constexpr (DLDS)
-        asm volatile("" : "+v"(zl));
       q_s[ab] = u[k];
       slice_sync();
       double qr = 0.0, qs = 0.0, qt = 0.0;
 #pragma unroll
       for (int mm = 0; mm < ND; ++mm)
       {
-        qr += DA(mm) * q_s[mm * ND + b];  // d/dx: sum over a, :195-199
-        qs += DB(mm) * q_s[a * ND + mm];  // d/dy: sum over b, :206-210
+        qr += Da[mm] * q_s[mm * ND + b];  // d/dx: sum over a, :195-199
+        qs += Db[mm] * q_s[a * ND + mm];  // d/dy: sum over b, :206-210
         qt += Dg[k * ND + mm] * u[mm];    // d/dz: registers, uniform table, :214-218
       }
       const double fr = kap * (g01.x * qr + g01.y * qs + g23.x * qt); // :233
@@ -622,8 +573,8 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
 #pragma unroll
       for (int mm = 0; mm < ND; ++mm)
       {
-        acc += DTA(mm) * gr_s[mm * ND + b]; // :246-251
-        acc += DTB(mm) * gs_s[a * ND + mm]; // :255-259
+        acc += DTa[mm] * gr_s[mm * ND + b]; // :246-251
+        acc += DTb[mm] * gs_s[a * ND + mm]; // :255-259
         Aq[mm] += Dg[k * ND + mm] * ft;     // :263-267
       }
       Aq[k] += acc;
@@ -639,9 +590,6 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
       atomicAdd(&sy[l[k]], contributes ? Aq[k] : 0.0); // :270,277 -- in LDS (ds_add_f64)
   }
   lds_barrier();
-#ifdef PMG_STAMPS
-  unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
-#endif
 
   // ---- write back (plain stores; the accumulator started from the earlier colours' y)
 #pragma unroll
@@ -652,17 +600,6 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
     {
       const uint32_t mk = pdofs[off + i];
       const uint32_t dof = mk & PD_MASK;
-      if (PMG_ABL & 2)
-      {
-        if (sy[i] == 1.2345e300)
-          y[dof] = 0.0;
-        continue;
-      }
-      if (PMG_ABL & 1)
-      {
-        __builtin_nontemporal_store(sy[i], &y[(size_t)p * MAXM + i]);
-        continue;
-      }
       if (mk & PD_BC)
       {
         if (!(mk & PD_ACC))
@@ -679,18 +616,6 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, PMG_WPS)
       }
     }
   }
-#ifdef PMG_STAMPS
-  __builtin_amdgcn_s_waitcnt(0); // vmcnt(0): stores acknowledged
-  unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
-  if (t == 0 && pmg_stamp_buf)
-  {
-    unsigned long long* o = pmg_stamp_buf + (size_t)p * 4;
-    o[0] = st0;
-    o[1] = st1;
-    o[2] = st2;
-    o[3] = st3;
-  }
-#endif
 }
 __global__ void zero_list_kernel(int n, const int32_t* __restrict__ idx, double* __restrict__ y)
 {
@@ -1393,10 +1318,3 @@ extern "C" int pmg_laplacian_launches_per_apply(pmg_laplacian op)
   return op ? (int)op->launch_first.size() : -1;
 }
 
-#ifdef PMG_STAMPS
-extern "C" int pmg_debug_set_stamp_buffer(unsigned long long* buf)
-{
-  PMG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pmg_stamp_buf), &buf, sizeof(buf)));
-  return PMG_OK;
-}
-#endif

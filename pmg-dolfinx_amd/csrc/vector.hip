@@ -460,11 +460,7 @@ namespace pmg
 {
 // a level streams (nt policy of the smoother kernels) when its vectors cannot stay in the
 // 256 MB MALL between kernels: from 4 M dofs (32 MB per vector, eight vectors in play)
-#ifdef PMG_NO_NT
-static inline bool streams(int) { return false; }
-#else
 static inline bool streams(int n) { return n >= (4 << 20); }
-#endif
 
 void launch_axpy(int n, double* r, double alpha, const double* x, const double* y, hipStream_t s)
 {
