@@ -548,7 +548,15 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
+    # release the library objects (and with them the RCCL communicator) while the runtime is still up
+    del H, x, b, u, y, op
+    comm = None
+    import gc
+
+    gc.collect()
+    torch.cuda.synchronize()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     if parity_failures:
         sys.exit(1)

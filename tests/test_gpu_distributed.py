@@ -135,6 +135,28 @@ def _rank_checks(pm, rank, world, n, dims, orders, comm=None):
                      abs(rn - mg.rnorm) / mg.rnorm))
     out["vcycle_err"] = verr
     out["eig_ref"] = eigs
+    # the coarsest level solved by CG + AMG (each rank's hierarchy on its own block: a block preconditioner
+    # for the distributed Krylov solve) against the oracle's cycle with an exact coarse solve
+    import scipy.sparse.linalg as spla
+
+    lu = spla.splu(ops[0].assemble_csr().tocsc())
+
+    def exact(u0, b0):
+        u0[:] = lu.solve(b0)
+
+    mgo = po.MultigridPreconditioner(ops, sm, it, mesh.boundary_marker(orders[0]), coarse_solver=exact)
+    amg = pm.AmgSolver(H.operators[0], max_iter=100, rtol=1e-11)
+    H.mg.set_coarse_solver(amg)
+    xv.set(0.0)
+    xo = np.zeros_like(b)
+    aerr = []
+    for _ in range(2):
+        H.mg.apply(H.rhs[-1], xv)
+        xo = mgo.apply(b, xo)
+        ref = xo[lvf.local_to_global[: lvf.size_local]]
+        aerr.append(float(np.abs(xv.data_copy()[: lvf.size_local] - ref).max() / np.abs(xo).max()))
+    out["amg_vcycle_err"] = aerr
+    H.mg.set_coarse_solver(None)
     return out
 
 
@@ -146,6 +168,7 @@ def _assert_rank_results(res):
             assert abs(got[1] - ref[1]) < 1e-8 * ref[1]
         for e, rn in out["vcycle_err"]:
             assert e < 1e-10 and rn < 1e-8
+        assert max(out["amg_vcycle_err"]) < 1e-7, out["amg_vcycle_err"]
 
 
 def _worker_body(rank, world, port, n, dims, orders):
