@@ -113,8 +113,17 @@ def main():
     n_global = tuple(args.n * d for d in dims) if args.scaling == "weak" else (args.n,) * 3
     # one process per GPU: the library's RCCL communicator (grouped ncclSend/ncclRecv per halo, ncclAllReduce
     # on device scalars), bootstrapped over the torch.distributed group the launcher gave us
-    comm = pm.RcclComm.from_torch(device=torch.device("cuda", local_rank)) if (world > 1 and args.exchange == "native") \
-        else None
+    comm, comm_note = None, None
+    if world > 1 and args.exchange == "native":
+        try:
+            comm = pm.RcclComm.from_torch(device=torch.device("cuda", local_rank))
+        except Exception as e:  # e.g. no librccl to bind: every rank fails alike; the callback route still is RCCL
+            comm_note = f"native communicator unavailable ({type(e).__name__}: {e}); torch.distributed callbacks"
+            log(f"[rank {rank}] {comm_note}")
+        ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            comm = None  # all ranks on the same route
 
     t0 = time.time()
     H = pm.PoissonHierarchy(n_global, orders, kappa=2.0, cheb_its=args.cheb, proc_dims=dims, rank=rank, size=world,
@@ -237,7 +246,7 @@ def main():
             "cheb_iterations": args.cheb,
             "partition": "x".join(str(d) for d in dims) + " bricks, 1 ghost-cell layer",
             "exchange": ("library RCCL communicator (grouped send/recv, device all-reduce)" if comm is not None
-                         else "torch.distributed callbacks") if world > 1 else "none (single rank)",
+                         else (comm_note or "torch.distributed callbacks")) if world > 1 else "none (single rank)",
             "stiffness_launches_per_cycle": {f"p{p}": c for p, c in zip(orders, counts)},
         },
         "roofline": roofline,
