@@ -62,6 +62,12 @@ class extra:
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Libraries underneath write to the process's stdout on their own
+    # (RCCL prints a version banner when a communicator is created), so file descriptor 1 is pointed at stderr
+    # for the whole run and the line goes out through a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -80,6 +86,9 @@ def main():
                     help="N > 1: halo + reductions on the library's own RCCL communicator (default) or through "
                          "torch.distributed callbacks")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaled config-3 measurement")
+    ap.add_argument("--rehearse-comm", action="store_true",
+                    help="N = 1: run the multi-rank code path (process group, communicator bootstrap, strong-scaling "
+                         "block) with a group of one rank -- a rehearsal on a single-GPU box, not a measurement")
     ap.add_argument("--mesh-sweep", action="store_true",
                     help="N = 1: PCG iteration counts at 32^3 / 64^3 / 96^3 with a random right-hand side")
     args = ap.parse_args()
@@ -99,12 +108,14 @@ def main():
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
 
-    if world > 1:
+    multi = world > 1 or args.rehearse_comm
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if rank == 0:
         ge.build()
-    if world > 1:
+    if multi:
         dist.barrier()
     import pmg_dolfinx_amd as pm
 
@@ -114,7 +125,7 @@ def main():
     # one process per GPU: the library's RCCL communicator (grouped ncclSend/ncclRecv per halo, ncclAllReduce
     # on device scalars), bootstrapped over the torch.distributed group the launcher gave us
     comm, comm_note = None, None
-    if world > 1 and args.exchange == "native":
+    if multi and args.exchange == "native":
         try:
             comm = pm.RcclComm.from_torch(device=torch.device("cuda", local_rank))
         except Exception as e:  # e.g. no librccl to bind: every rank fails alike; the callback route still is RCCL
@@ -140,7 +151,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,7 +164,7 @@ def main():
         H.mg.apply(b, x)
     sync_all()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -162,7 +173,7 @@ def main():
     counts = H.mg.apply_counts()
     # the same K cycles replayed as a hipGraph (one launch per cycle instead of ~120; single rank only)
     graph_ms = None
-    if world == 1:
+    if not multi:
         H.mg.set_graph(True)
         for _ in range(2):
             H.mg.apply(b, x)
@@ -246,7 +257,7 @@ def main():
             "cheb_iterations": args.cheb,
             "partition": "x".join(str(d) for d in dims) + " bricks, 1 ghost-cell layer",
             "exchange": ("library RCCL communicator (grouped send/recv, device all-reduce)" if comm is not None
-                         else (comm_note or "torch.distributed callbacks")) if world > 1 else "none (single rank)",
+                         else (comm_note or "torch.distributed callbacks")) if multi else "none (single rank)",
             "stiffness_launches_per_cycle": {f"p{p}": c for p, c in zip(orders, counts)},
         },
         "roofline": roofline,
@@ -263,7 +274,7 @@ def main():
             Hx.mg.apply(bx, xx)
         sync_all()
         t = time.perf_counter() - t
-        if world > 1:
+        if multi:
             tt = torch.tensor([t], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t = float(tt.item())
@@ -271,7 +282,7 @@ def main():
 
     # ---- BASELINE config 3 (N > 1): the SAME 64^3 problem split over the N GPUs (strong scaling), next to the
     # weak-scaled headline.  Not `value`.
-    if world > 1 and args.scaling == "weak" and not args.no_strong:
+    if multi and args.scaling == "weak" and not args.no_strong:
         Hs = pm.PoissonHierarchy((args.n,) * 3, orders, kappa=2.0, cheb_its=args.cheb, proc_dims=dims, rank=rank,
                                  size=world, comm=comm)
         xs_ = Hs.new_vector()
@@ -302,7 +313,7 @@ def main():
                                "residual_contraction_per_cycle": [round(c, 4) for c in _contraction()[0]]}}
         t_setup = time.perf_counter()
         modes = [("krylov", dict(max_iter=60, rtol=1e-5))]
-        if world == 1:
+        if not multi:
             modes.append(("stationary_2_cycles", dict(cycles=2)))
         for name, kw in modes:
             amg = pm.AmgSolver(H.operators[0], **kw)
@@ -333,14 +344,14 @@ def main():
         g = np.random.default_rng(1000 + rank).standard_normal(lvf.ndofs)
         g[lvf.bc_marker.astype(bool)] = 0.0
         brand.data.copy_(torch.from_numpy(g))
-        amg = pm.AmgSolver(H.operators[0], cycles=2) if world == 1 else pm.AmgSolver(H.operators[0])
+        amg = pm.AmgSolver(H.operators[0], cycles=2) if not multi else pm.AmgSolver(H.operators[0])
         for name, rhs in (("random_rhs", brand), ("manufactured_rhs", b), ("random_rhs_amg_coarse", brand)):
             cg = pm.CGSolver(H.layouts[-1])
             cg.set_max_iterations(200)
             cg.set_tolerance(1e-8)
             if name.endswith("amg_coarse"):
                 H.mg.set_coarse_solver(amg)
-                cg.set_flexible(world > 1)  # Krylov coarse solve on several ranks: not a fixed linear operator
+                cg.set_flexible(multi)  # Krylov coarse solve on several ranks: not a fixed linear operator
             xs = H.new_vector()
             xs.set(0.0)
             sync_all()
@@ -556,7 +567,8 @@ def main():
         out["value"] = None  # a fast wrong answer is not a measurement
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     # release the library objects (and with them the RCCL communicator) while the runtime is still up
     del H, x, b, u, y, op
     comm = None
@@ -564,7 +576,7 @@ def main():
 
     gc.collect()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if parity_failures:

@@ -185,6 +185,8 @@ namespace pmg
 int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s)
 {
   pmg_comm c = l->comm;
+  if (l->nb_rank.empty()) // no partner: nothing to post (point-to-point groups are not collectives)
+    return PMG_OK;
   PMG_HIP(hipEventRecord(l->ev_packed, s));
   PMG_HIP(hipStreamWaitEvent(c->stream, l->ev_packed, 0));
   const double* out = reverse ? l->recv_buf : l->send_buf;
@@ -212,6 +214,8 @@ int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s)
 
 int comm_exchange_end(pmg_layout l, hipStream_t s)
 {
+  if (l->nb_rank.empty())
+    return PMG_OK;
   PMG_HIP(hipStreamWaitEvent(s, l->ev_arrived, 0));
   return PMG_OK;
 }
