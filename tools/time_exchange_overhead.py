@@ -1,7 +1,9 @@
-"""Host-side cost of the RCCL exchange path: the config-2 V-cycle on one GPU with every
-halo scatter going through torch.distributed (nccl, world size 1, zero-length messages),
-against the same cycle without callbacks.  Shows whether the Python callbacks can make
-the multi-GPU cycle host-bound.   usage: python tools/time_exchange_overhead.py"""
+"""Cost of the halo path on ONE GPU: the config-2 V-cycle of rank 0 of a 1x1x2 split (64^3 owned cells plus
+the ghost layer; every scatter packs / exchanges / unpacks the real halo volume, ~2 MB at p4) with the rank as
+its own partner, through (a) the library's RCCL communicator, (b) callbacks into torch.distributed, against
+(c) the same brick without any exchange.  The numerics are meaningless (ghosts receive the wrong owned values);
+the timings are not: host issue time per cycle, cycle time, i.e. what the exchange costs before any xGMI
+link is involved.   usage: python tools/time_exchange_overhead.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,13 +31,32 @@ def cycle_ms(H, reps=20):
     return (time.perf_counter() - t0) / reps * 1e3, t_issue / reps * 1e3
 
 
-H = pm.PoissonHierarchy(64, (1, 2, 4), cheb_its=3)
-print("no callbacks:   %.3f ms per cycle (host issue time %.3f ms)" % cycle_ms(H))
-del H
+def self_layout(comm_factory):
+    def make(lv, group=None, device="cuda", comm=None):
+        m = min(sum(lv.send_counts), sum(lv.recv_counts))
+        c = comm_factory()
+        return pm.Layout(lv.size_local, lv.num_ghosts, [0] if m else [], [m] if m else [], [m] if m else [],
+                         lv.send_indices[:m], lv.recv_indices[:m], device=device, comm=c,
+                         always_exchange=c is None)
+    return make
+
+
 orig = problem.make_layout
-problem.make_layout = lambda lv, group=None, device="cuda": pm.Layout(
-    lv.size_local, lv.num_ghosts, lv.neighbors, lv.send_counts, lv.recv_counts, lv.send_indices, lv.recv_indices,
-    group=group, device=device, always_exchange=True)
-H = pm.PoissonHierarchy(64, (1, 2, 4), cheb_its=3)
-print("rccl callbacks: %.3f ms per cycle (host issue time %.3f ms)" % cycle_ms(H))
+build = lambda: pm.PoissonHierarchy((64, 64, 128), (1, 2, 4), cheb_its=3, proc_dims=(1, 1, 2), rank=0, size=2)
+
+problem.make_layout = lambda lv, group=None, device="cuda", comm=None: pm.Layout(lv.size_local, lv.num_ghosts, device=device)
+H = build()
+print("ghost dofs per level:", [lv.num_ghosts for lv in H.levels], " halo bytes at p4: %.2f MB" % (H.levels[-1].num_ghosts * 8e-6))
+print("no exchange:             %.3f ms per cycle (host issue time %.3f ms)" % cycle_ms(H))
+del H
+native = pm.RcclComm(0, 1, pm.RcclComm.unique_id())
+problem.make_layout = self_layout(lambda: native)
+H = build()
+print("library RCCL communicator: %.3f ms per cycle (host issue time %.3f ms)" % cycle_ms(H))
+del H
+problem.make_layout = self_layout(lambda: None)
+H = build()
+print("torch.distributed callbacks: %.3f ms per cycle (host issue time %.3f ms)" % cycle_ms(H))
+del H
+problem.make_layout = orig
 dist.destroy_process_group()
