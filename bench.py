@@ -308,15 +308,21 @@ def main():
         rns = [H.mg.apply(b, xc_, verbose=True) for _ in range(k)]
         return [rns[i + 1] / rns[i] for i in range(k - 1)], xc_
 
+    def make_amg(**kw):
+        """The coarse solver: on several ranks the replicated hierarchy (global degree-1 matrix on every rank,
+        one all-reduce per solve), on one rank the plain one."""
+        if multi:
+            return pm.AmgSolver(H.operators[0], global_index=H.levels[0].local_to_global,
+                                n_global=H.part.global_ndofs(orders[0]), **kw)
+        return pm.AmgSolver(H.operators[0], **kw)
+
     def _amg_coarse():
         res = {"plain_cycle": {"coarse": "Chebyshev smoother (reference default)", "ms_per_step": ms_per_step,
                                "residual_contraction_per_cycle": [round(c, 4) for c in _contraction()[0]]}}
         t_setup = time.perf_counter()
-        modes = [("krylov", dict(max_iter=60, rtol=1e-5))]
-        if not multi:
-            modes.append(("stationary_2_cycles", dict(cycles=2)))
+        modes = [("krylov", dict(max_iter=60, rtol=1e-5)), ("stationary_2_cycles", dict(cycles=2))]
         for name, kw in modes:
-            amg = pm.AmgSolver(H.operators[0], **kw)
+            amg = make_amg(**kw)
             torch.cuda.synchronize()
             setup_s = time.perf_counter() - t_setup
             H.mg.set_coarse_solver(amg)
@@ -344,14 +350,14 @@ def main():
         g = np.random.default_rng(1000 + rank).standard_normal(lvf.ndofs)
         g[lvf.bc_marker.astype(bool)] = 0.0
         brand.data.copy_(torch.from_numpy(g))
-        amg = pm.AmgSolver(H.operators[0], cycles=2) if not multi else pm.AmgSolver(H.operators[0])
+        amg = make_amg(cycles=2)
         for name, rhs in (("random_rhs", brand), ("manufactured_rhs", b), ("random_rhs_amg_coarse", brand)):
             cg = pm.CGSolver(H.layouts[-1])
             cg.set_max_iterations(200)
             cg.set_tolerance(1e-8)
             if name.endswith("amg_coarse"):
                 H.mg.set_coarse_solver(amg)
-                cg.set_flexible(multi)  # Krylov coarse solve on several ranks: not a fixed linear operator
+                cg.set_flexible(False)  # stationary AMG cycles: the V-cycle stays a fixed linear operator
             xs = H.new_vector()
             xs.set(0.0)
             sync_all()

@@ -234,7 +234,11 @@ void solve(const Options& o)
   if (o.use_amg)
   {
     auto t0 = std::chrono::steady_clock::now();
-    coarse_solver = std::make_shared<CoarseSolverType<T>>(*operators[0], maps[0]);
+    if (size > 1) // the global degree-1 matrix on every rank: one all-reduce per coarse solve
+      coarse_solver = std::make_shared<CoarseSolverType<T>>(*operators[0], maps[0], V[0]->lv.local_to_global,
+                                                           mesh.global_ndofs(order[0]));
+    else
+      coarse_solver = std::make_shared<CoarseSolverType<T>>(*operators[0], maps[0]);
     if (o.amg_cycles > 0)
       coarse_solver->set_cycles(o.amg_cycles);
     if (root)
@@ -309,7 +313,7 @@ void solve(const Options& o)
     cg.set_max_iterations(100);
     cg.set_tolerance(1e-8);
     // with a Krylov coarse solve inside, the cycle is not a fixed linear operator
-    cg.set_flexible(o.coarse_cg || (o.use_amg && o.amg_cycles == 0));
+    cg.set_flexible(o.coarse_cg || (o.use_amg && o.amg_cycles == 0)); // (stationary AMG cycles: a fixed operator)
     DeviceVector rhs(maps.back(), 1);
     if (o.random_rhs)
     {

@@ -352,9 +352,17 @@ int pmg_multigrid_set_coarse_callback(pmg_multigrid mg, pmg_coarse_solve_fn solv
  *     by one AMG V-cycle, zero initial guess, max_iter / rtol as set (60, 1e-5); or
  *   - stationary mode (pmg_amg_set_cycles(n > 0)): n AMG V-cycles from a zero initial guess -- a
  *     fixed linear operator without host synchronisation (single rank only).
- * `op` must be a degree-1 operator and outlive the solver.  On several ranks the hierarchy is built
- * on the rank's own block (ghost couplings dropped from the preconditioner only). */
+ * `op` must be a degree-1 operator and outlive the solver.
+ * Several ranks: pmg_amg_create builds the hierarchy of the rank's own block (a block preconditioner
+ * for the Krylov mode; iteration counts grow with the number of ranks).  pmg_amg_create_replicated
+ * gathers the owned rows of all ranks -- `global_index` [size_local + num_ghosts] (host) is the global
+ * number of every local dof, dolfinx's IndexMap::local_to_global; n_global < 2^31 -- into the global
+ * matrix on every rank: a solve is then one all-reduce of the zero-padded right-hand side (on the
+ * layout's communicator, or through its allreduce callback) and the single-rank solve of the whole
+ * coarse problem on every rank; both modes work, with one rank's iteration counts.  Collective. */
 int pmg_amg_create(pmg_amg* out, pmg_laplacian op, pmg_stream stream);
+int pmg_amg_create_replicated(pmg_amg* out, pmg_laplacian op, const int64_t* global_index, int64_t n_global,
+                              pmg_stream stream);
 int pmg_amg_destroy(pmg_amg amg);
 int pmg_amg_set_smoother_iterations(pmg_amg amg, int k); /* Chebyshev degree per pre/post smooth (2) */
 int pmg_amg_set_cycles(pmg_amg amg, int cycles);

@@ -611,6 +611,16 @@ public:
   {
     check(pmg_amg_create(&_a, coarse_operator.handle(map), nullptr));
   }
+  /// Several ranks: the global coarse matrix gathered on every rank (`local_to_global` as dolfinx's
+  /// IndexMap gives it: owned dofs, then ghosts), one all-reduce per solve.
+  template <typename Operator>
+  AmgSolver(Operator& coarse_operator, const std::shared_ptr<const IndexMap>& map,
+            std::span<const std::int64_t> local_to_global, std::int64_t size_global)
+  {
+    if ((std::int64_t)local_to_global.size() != (std::int64_t)map->size_local() + map->num_ghosts())
+      throw std::runtime_error("AmgSolver: local_to_global must cover owned and ghost dofs");
+    check(pmg_amg_create_replicated(&_a, coarse_operator.handle(map), local_to_global.data(), size_global, nullptr));
+  }
   AmgSolver(const AmgSolver&) = delete;
   AmgSolver& operator=(const AmgSolver&) = delete;
   ~AmgSolver() { pmg_amg_destroy(_a); }

@@ -20,10 +20,20 @@ class AmgSolver:
     ``cycles=n``: stationary mode, n AMG V-cycles from a zero initial guess -- a fixed linear
     operator with no host synchronisation (single rank)."""
 
-    def __init__(self, op, max_iter: int = 60, rtol: float = 1e-5, cycles: int = 0, smoother_iterations: int = 2):
+    def __init__(self, op, max_iter: int = 60, rtol: float = 1e-5, cycles: int = 0, smoother_iterations: int = 2,
+                 global_index=None, n_global=None):
+        """``global_index`` (local -> global dof numbers, owned then ghosts) and ``n_global``: the replicated
+        form for several ranks -- the global coarse matrix gathered on every rank, one all-reduce per solve."""
         self.op = op  # must outlive the handle
         h = vp()
-        call("pmg_amg_create", C.byref(h), op.handle, current_stream())
+        if global_index is not None:
+            gi = np.ascontiguousarray(global_index, dtype=np.int64)
+            if gi.size != op.layout.total:
+                raise ValueError("global_index must have size_local + num_ghosts entries")
+            call("pmg_amg_create_replicated", C.byref(h), op.handle, gi.ctypes.data_as(C.POINTER(C.c_int64)),
+                 int(n_global), current_stream())
+        else:
+            call("pmg_amg_create", C.byref(h), op.handle, current_stream())
         self._handle = h
         call("pmg_amg_set_smoother_iterations", h, int(smoother_iterations))
         if cycles > 0:

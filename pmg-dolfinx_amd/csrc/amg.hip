@@ -21,10 +21,15 @@
 //     reference's shape -- CG on the matrix-free operator preconditioned by one cycle, to a
 //     relative tolerance, at most max_iter iterations.
 //
-// Several ranks: each rank's hierarchy is built on its owned-rows x owned-columns block (the ghost
-// couplings are dropped from the preconditioner, not from the operator), so the Krylov solve --
-// whose operator is the distributed matrix-free Laplacian -- converges to the global solution with
-// a block preconditioner.  A hierarchy that aggregates across ranks is the next step.
+// Several ranks, two forms.  Replicated (pmg_amg_create_replicated, what the harness uses): the owned
+// rows are gathered once, with global column indices, into the global degree-1 matrix on every rank
+// (coarse-grid agglomeration); a solve is ONE all-reduce of the zero-padded right-hand side followed by
+// the single-rank solve of the whole coarse problem on every rank -- identical arithmetic everywhere, no
+// communication inside, the same iteration counts as on one rank.  The degree-1 level is 1/64 of the
+// p = 4 dofs, so the redundant work stays small next to a fine-level smooth.  Rank-local
+// (pmg_amg_create on a distributed operator): the hierarchy of the rank's owned block as a block
+// preconditioner of a distributed Krylov solve (ghost couplings dropped from the preconditioner only):
+// no gather, but 9 -> 31 -> 38 -> 40 CG iterations on 1 -> 2 -> 4 -> 8 ranks (tools/amg_rank_scaling.py).
 //
 // Parity: unpinned by the reference (third-party arithmetic, no fixture).  The tests compare the
 // device cycle with a numpy restatement of the same hierarchy (oracle/amg_oracle.py) and check the
@@ -486,6 +491,15 @@ struct pmg_amg_s
   pmg_cg cg = nullptr;  // work vectors of the Krylov mode
   double* xc = nullptr; // stationary mode with several cycles: correction
   int last_iterations = 0;
+  // Replicated form (several ranks): the hierarchy is built on the GATHERED global matrix, every rank
+  // solves the whole coarse problem (one all-reduce of the zero-padded right-hand side per solve, no
+  // communication inside the solve); gid = global index of the owned dofs
+  bool replicated = false;
+  int32_t n_global = 0;
+  int32_t* gid = nullptr;       // [size_local] device
+  double *gb = nullptr, *gx = nullptr; // [n_global] device
+  double* h_stage = nullptr;    // pinned, [n_global]: the callback route of the all-reduce
+  pmg_layout glayout = nullptr; // the replicated problem seen as one rank's (Krylov work vectors)
   // host copy of the hierarchy for pmg_amg_export (tests)
   std::vector<HostCsr> hA, hP;
   std::vector<double> hlmax;
@@ -532,26 +546,80 @@ int amg_cycle(pmg_amg amg, int l, double* x, const double* b, hipStream_t s)
 }
 } // namespace
 
+namespace
+{
+// scatter the owned entries into a zero global vector / read them back
+__global__ void to_global_kernel(int n, const int32_t* __restrict__ gid, const double* __restrict__ v,
+                                 double* __restrict__ g)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    g[gid[i]] = v[i];
+}
+__global__ void from_global_kernel(int n, const int32_t* __restrict__ gid, const double* __restrict__ g,
+                                   double* __restrict__ v)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    v[i] = g[gid[i]];
+}
+
+// sum a host array over the ranks of a layout (set-up only; chunks that fit the transports)
+int host_allreduce_sum(pmg_layout l, double* v, size_t n, hipStream_t s)
+{
+  if (!l->multi_rank() || n == 0)
+    return PMG_OK;
+  const size_t chunk = (size_t)1 << 24;
+  if (l->comm)
+  {
+    double* d = nullptr;
+    PMG_HIP(hipMalloc(&d, sizeof(double) * std::min(n, chunk)));
+    int rc = PMG_OK;
+    for (size_t o = 0; o < n && rc == PMG_OK; o += chunk)
+    {
+      const size_t m = std::min(chunk, n - o);
+      if (hipMemcpyAsync(d, v + o, sizeof(double) * m, hipMemcpyHostToDevice, s) != hipSuccess)
+        rc = fail(PMG_ERR_HIP, "host_allreduce_sum: copy failed");
+      if (rc == PMG_OK)
+        rc = comm_allreduce(l, d, (int)m, false, s);
+      if (rc == PMG_OK && hipMemcpyAsync(v + o, d, sizeof(double) * m, hipMemcpyDeviceToHost, s) != hipSuccess)
+        rc = fail(PMG_ERR_HIP, "host_allreduce_sum: copy failed");
+      if (rc == PMG_OK && hipStreamSynchronize(s) != hipSuccess)
+        rc = fail(PMG_ERR_HIP, "host_allreduce_sum: synchronise failed");
+    }
+    (void)hipFree(d);
+    return rc;
+  }
+  for (size_t o = 0; o < n; o += chunk)
+    if (l->allreduce(l->user, v + o, (int)std::min(chunk, n - o)) != 0)
+      return fail(PMG_ERR_INVALID, "allreduce callback failed");
+  return PMG_OK;
+}
+
+int build_hierarchy(pmg_amg amg, HostCsr&& A0, size_t level0_len);
+} // namespace
+
 namespace pmg
 {
 pmg_layout amg_layout(pmg_amg amg) { return amg->layout; }
 
-// stationary cycles are stream-ordered and capturable; the Krylov mode synchronises the host
+// stationary cycles are stream-ordered and capturable; the Krylov mode synchronises the host (and so
+// does the callback route of the replicated form's all-reduce)
 long long amg_capture_state(pmg_amg amg)
 {
-  return amg->cycles > 0 ? ((long long)amg->cycles << 16) ^ amg->smoother_its : -1;
+  if (amg->cycles <= 0 || (amg->replicated && !amg->layout->comm && amg->layout->allreduce))
+    return -1;
+  return ((long long)amg->cycles << 16) ^ amg->smoother_its ^ (amg->replicated ? 1 << 30 : 0);
 }
+} // namespace pmg
 
-// x = (approximately) A^-1 b on the coarsest p-level, x zero on entry is not assumed
-int amg_solve(pmg_amg amg, double* x, const double* b, hipStream_t s)
+namespace
 {
-  Range range("pmg:amg_solve");
-  pmg_layout l = amg->layout;
-  const int n = l->size_local;
+// the solve on one rank's vectors of n entries: `A` is the operator of the Krylov mode
+int solve_on(pmg_amg amg, double* x, const double* b, int n, size_t total, const ApplyFn& A, hipStream_t s)
+{
   if (amg->cycles > 0)
   {
-    PMG_REQUIRE(!l->multi_rank(), "pmg_amg: the stationary mode is a single-rank solver (the hierarchy is built "
-                                  "on the rank's own block); use the Krylov mode on several ranks");
     PMG_TRY(amg_cycle(amg, 0, x, b, s));
     AmgLevel& l0 = amg->levels[0];
     for (int c = 1; c < amg->cycles; ++c) // x += cycle(b - A x)
@@ -564,17 +632,64 @@ int amg_solve(pmg_amg amg, double* x, const double* b, hipStream_t s)
     return PMG_OK;
   }
   // the reference's shape: CG (<= max_iter, rtol) on the operator, preconditioned by one cycle
-  PMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * l->total(), s)); // KSP-style zero initial guess
-  pmg_laplacian op = amg->op;
-  const ApplyFn A = [op, s](double* in, double* out) { return laplacian_apply(op, in, out, s); };
+  PMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * total, s)); // KSP-style zero initial guess
   const PrecondFn M = [amg, s](double* z, const double* r) { return amg_cycle(amg, 0, z, r, s); };
   PMG_TRY(pmg_cg_set_max_iterations(amg->cg, amg->max_iter));
   PMG_TRY(pmg_cg_set_tolerance(amg->cg, amg->rtol));
   return cg_iterate(amg->cg, A, nullptr, &M, false, x, b, &amg->last_iterations, s);
 }
+} // namespace
+
+namespace pmg
+{
+// x = (approximately) A^-1 b on the coarsest p-level, x zero on entry is not assumed
+int amg_solve(pmg_amg amg, double* x, const double* b, hipStream_t s)
+{
+  Range range("pmg:amg_solve");
+  pmg_layout l = amg->layout;
+  const int n = l->size_local;
+  if (amg->replicated)
+  {
+    // gather the right-hand side (zero-padded global vector, summed over the ranks), solve the WHOLE
+    // coarse problem on every rank -- identical arithmetic everywhere, no communication inside -- and keep
+    // the owned entries
+    const int ng = amg->n_global;
+    PMG_HIP(hipMemsetAsync(amg->gb, 0, sizeof(double) * ng, s));
+    if (n > 0)
+      to_global_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, amg->gid, b, amg->gb);
+    PMG_HIP(hipGetLastError());
+    if (l->comm)
+      PMG_TRY(comm_allreduce(l, amg->gb, ng, false, s));
+    else if (l->allreduce)
+    {
+      PMG_HIP(hipMemcpyAsync(amg->h_stage, amg->gb, sizeof(double) * ng, hipMemcpyDeviceToHost, s));
+      PMG_HIP(hipStreamSynchronize(s));
+      for (size_t o = 0; o < (size_t)ng; o += (size_t)1 << 24)
+        if (l->allreduce(l->user, amg->h_stage + o, (int)std::min<size_t>((size_t)1 << 24, ng - o)) != 0)
+          return fail(PMG_ERR_INVALID, "allreduce callback failed");
+      PMG_HIP(hipMemcpyAsync(amg->gb, amg->h_stage, sizeof(double) * ng, hipMemcpyHostToDevice, s));
+    }
+    AmgLevel& l0 = amg->levels[0];
+    const ApplyFn A = [&l0, s](double* in, double* out) { return csr_product<0>(l0.A, in, nullptr, out, s); };
+    PMG_TRY(solve_on(amg, amg->gx, amg->gb, ng, (size_t)ng, A, s));
+    if (n > 0)
+      from_global_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, amg->gid, amg->gx, x);
+    PMG_HIP(hipGetLastError());
+    return PMG_OK;
+  }
+  PMG_REQUIRE(amg->cycles == 0 || !l->multi_rank(),
+              "pmg_amg: stationary cycles of a rank-local hierarchy are a single-rank solver; on several ranks "
+              "use the Krylov mode or the replicated hierarchy (pmg_amg_create_replicated)");
+  pmg_laplacian op = amg->op;
+  const ApplyFn A = [op, s](double* in, double* out) { return laplacian_apply(op, in, out, s); };
+  return solve_on(amg, x, b, n, (size_t)l->total(), A, s);
+}
 } // namespace pmg
 
-extern "C" int pmg_amg_create(pmg_amg* out, pmg_laplacian op, pmg_stream stream)
+
+// `global_index` == nullptr: the hierarchy of this rank's own block.  Otherwise the replicated form.
+static int amg_create(pmg_amg* out, pmg_laplacian op, const int64_t* global_index, int64_t n_global,
+                      pmg_stream stream)
 {
   PMG_REQUIRE(out && op, "pmg_amg_create: NULL argument");
   const LaplacianInputs in = laplacian_inputs(op);
@@ -582,10 +697,20 @@ extern "C" int pmg_amg_create(pmg_amg* out, pmg_laplacian op, pmg_stream stream)
   hipStream_t s = S(stream);
   pmg_layout layout = laplacian_layout(op);
   const int n = layout->size_local, total = layout->total();
+  const bool replicated = global_index != nullptr;
+  if (replicated)
+  {
+    PMG_REQUIRE(n_global >= n && n_global < ((int64_t)1 << 31), "pmg_amg_create_replicated: bad global size");
+    for (int i = 0; i < total; ++i)
+      PMG_REQUIRE(global_index[i] >= 0 && global_index[i] < n_global,
+                  "pmg_amg_create_replicated: global index %lld out of range", (long long)global_index[i]);
+  }
   auto* amg = new pmg_amg_s;
   HandleGuard<pmg_amg> guard(amg, pmg_amg_destroy);
   amg->op = op;
   amg->layout = layout;
+  amg->replicated = replicated;
+  amg->n_global = replicated ? (int32_t)n_global : 0;
 
   // ---- level 0: assemble the owned block of the degree-1 stiffness matrix ----
   std::vector<int32_t> dofmap((size_t)in.ncells * 8);
@@ -690,13 +815,14 @@ extern "C" int pmg_amg_create(pmg_amg* out, pmg_laplacian op, pmg_stream stream)
         for (int j = 0; j < 8; ++j)
         {
           const int col = dm[j];
-          if (col >= n || bc[col])
-            continue; // ghost columns: dropped from the preconditioner; Dirichlet columns: masked
+          if (bc[col] || (!replicated && col >= n))
+            continue; // Dirichlet columns: masked; ghost columns: dropped from a rank-local hierarchy
           add(row, col, Ke[i][j]);
         }
       }
     }
-    A0.n = A0.m = n;
+    A0.n = n;
+    A0.m = replicated ? total : n;
     A0.rp.assign(n + 1, 0);
     std::vector<std::pair<int, double>> row;
     for (int i = 0; i < n; ++i)
@@ -718,6 +844,91 @@ extern "C" int pmg_amg_create(pmg_amg* out, pmg_laplacian op, pmg_stream stream)
     }
   }
 
+  size_t level0_len = (size_t)total;
+  if (replicated)
+  {
+    // ---- gather: every rank contributes its owned rows with global column ids in fixed-width slots of
+    // a zero global table; the sum over the ranks is the global matrix (column + 1, so that 0 = empty)
+    int wloc = 0;
+    for (int i = 0; i < n; ++i)
+      wloc = std::max(wloc, A0.rp[i + 1] - A0.rp[i]);
+    // the maximum over the ranks, from sums: one slot per width would be wasteful, use a unary code
+    std::vector<double> wcode(256, 0.0);
+    PMG_REQUIRE(wloc < 256, "pmg_amg_create_replicated: a row with %d entries", wloc);
+    wcode[wloc] = 1.0;
+    PMG_TRY(host_allreduce_sum(layout, wcode.data(), wcode.size(), s));
+    int W = 1;
+    for (int w = 0; w < 256; ++w)
+      if (wcode[w] > 0.0)
+        W = std::max(W, w);
+    const size_t ng = (size_t)n_global;
+    std::vector<double> gc(ng * W, 0.0), gv(ng * W, 0.0);
+    for (int i = 0; i < n; ++i)
+    {
+      const size_t g = (size_t)global_index[i];
+      int k = 0;
+      for (int e = A0.rp[i]; e < A0.rp[i + 1]; ++e, ++k)
+      {
+        gc[g * W + k] = (double)(global_index[A0.ci[e]] + 1);
+        gv[g * W + k] = A0.v[e];
+      }
+    }
+    PMG_TRY(host_allreduce_sum(layout, gc.data(), gc.size(), s));
+    PMG_TRY(host_allreduce_sum(layout, gv.data(), gv.size(), s));
+    HostCsr Ag;
+    Ag.n = Ag.m = (int)ng;
+    Ag.rp.assign(ng + 1, 0);
+    std::vector<std::pair<int, double>> row;
+    for (size_t g = 0; g < ng; ++g)
+    {
+      row.clear();
+      for (int k = 0; k < W; ++k)
+        if (gc[g * W + k] > 0.5)
+          row.emplace_back((int)(gc[g * W + k] - 0.5), gv[g * W + k]);
+      PMG_REQUIRE(!row.empty(), "pmg_amg_create_replicated: global dof %zu is owned by no rank", g);
+      std::sort(row.begin(), row.end());
+      for (auto& e : row)
+      {
+        Ag.ci.push_back(e.first);
+        Ag.v.push_back(e.second);
+      }
+      Ag.rp[g + 1] = (int)Ag.ci.size();
+    }
+    A0 = std::move(Ag);
+    level0_len = ng;
+    std::vector<int32_t> gid(n);
+    for (int i = 0; i < n; ++i)
+      gid[i] = (int32_t)global_index[i];
+    PMG_TRY(to_device(&amg->gid, gid));
+    PMG_TRY(alloc_d(&amg->gb, ng));
+    PMG_TRY(alloc_d(&amg->gx, ng));
+    PMG_HIP(hipHostMalloc(&amg->h_stage, sizeof(double) * std::max<size_t>(ng, 1), hipHostMallocDefault));
+    PMG_TRY(pmg_layout_create(&amg->glayout, (int32_t)ng, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                              nullptr, nullptr));
+  }
+  PMG_TRY(build_hierarchy(amg, std::move(A0), level0_len));
+  PMG_TRY(pmg_cg_create(&amg->cg, replicated ? amg->glayout : layout));
+  PMG_HIP(hipStreamSynchronize(s));
+  *out = guard.release();
+  return PMG_OK;
+}
+
+extern "C" int pmg_amg_create(pmg_amg* out, pmg_laplacian op, pmg_stream stream)
+{
+  return amg_create(out, op, nullptr, 0, stream);
+}
+
+extern "C" int pmg_amg_create_replicated(pmg_amg* out, pmg_laplacian op, const int64_t* global_index,
+                                         int64_t n_global, pmg_stream stream)
+{
+  PMG_REQUIRE(global_index, "pmg_amg_create_replicated: NULL global index");
+  return amg_create(out, op, global_index, n_global, stream);
+}
+
+namespace
+{
+int build_hierarchy(pmg_amg amg, HostCsr&& A0, size_t level0_len)
+{
   // ---- the hierarchy ----
   const int max_levels = 12, coarsest_max = 800;
   std::vector<HostCsr> As, Ps;
@@ -765,7 +976,7 @@ extern "C" int pmg_amg_create(pmg_amg* out, pmg_laplacian op, pmg_stream stream)
       PMG_TRY(upload_csr(lv.P, Ps[l]));
       PMG_TRY(upload_csr(lv.R, transpose(Ps[l])));
     }
-    const size_t len = (l == 0) ? (size_t)total : (size_t)lv.n;
+    const size_t len = (l == 0) ? level0_len : (size_t)lv.n;
     PMG_TRY(alloc_d(&lv.r, len));
     PMG_TRY(alloc_d(&lv.z, len));
     PMG_TRY(alloc_d(&lv.q, len));
@@ -773,7 +984,7 @@ extern "C" int pmg_amg_create(pmg_amg* out, pmg_laplacian op, pmg_stream stream)
     if (l > 0)
       PMG_TRY(alloc_d(&lv.x, len));
   }
-  PMG_TRY(alloc_d(&amg->xc, (size_t)total));
+  PMG_TRY(alloc_d(&amg->xc, level0_len));
   // coarsest level: dense inverse when small enough
   {
     const HostCsr& Ac = As.back();
@@ -784,14 +995,12 @@ extern "C" int pmg_amg_create(pmg_amg* out, pmg_laplacian op, pmg_stream stream)
       PMG_TRY(to_device(&amg->dense_inv, inv));
     }
   }
-  PMG_TRY(pmg_cg_create(&amg->cg, layout));
   amg->hA = std::move(As);
   amg->hP = std::move(Ps);
   amg->hlmax = lmaxs;
-  PMG_HIP(hipStreamSynchronize(s));
-  *out = guard.release();
   return PMG_OK;
 }
+} // namespace
 
 extern "C" int pmg_amg_destroy(pmg_amg amg)
 {
@@ -811,7 +1020,13 @@ extern "C" int pmg_amg_destroy(pmg_amg amg)
   }
   (void)hipFree(amg->dense_inv);
   (void)hipFree(amg->xc);
+  (void)hipFree(amg->gid);
+  (void)hipFree(amg->gb);
+  (void)hipFree(amg->gx);
+  if (amg->h_stage)
+    (void)hipHostFree(amg->h_stage);
   pmg_cg_destroy(amg->cg);
+  pmg_layout_destroy(amg->glayout);
   delete amg;
   return PMG_OK;
 }
@@ -852,6 +1067,7 @@ extern "C" int pmg_amg_solve(pmg_amg amg, double* x, const double* b, int* itera
 extern "C" int pmg_amg_cycle(pmg_amg amg, double* x, const double* b, pmg_stream stream)
 {
   PMG_REQUIRE(amg && x && b && x != b, "pmg_amg_cycle: bad argument");
+  PMG_REQUIRE(!amg->replicated, "pmg_amg_cycle: a replicated hierarchy works on gathered vectors; use pmg_amg_solve");
   return amg_cycle(amg, 0, x, b, S(stream));
 }
 

@@ -156,6 +156,34 @@ def _rank_checks(pm, rank, world, n, dims, orders, comm=None):
         ref = xo[lvf.local_to_global[: lvf.size_local]]
         aerr.append(float(np.abs(xv.data_copy()[: lvf.size_local] - ref).max() / np.abs(xo).max()))
     out["amg_vcycle_err"] = aerr
+    # the replicated hierarchy (global coarse matrix on every rank, one all-reduce per solve): stationary
+    # cycles work on several ranks, and a Krylov solve takes exactly as many iterations as on one rank
+    lv0 = H.levels[0]
+    g = np.random.default_rng(5).standard_normal(H.part.global_ndofs(orders[0]))
+    g[mesh.boundary_marker(orders[0]).astype(bool)] = 0.0
+    bl = pm.Vector(H.layouts[0])
+    bl.data.copy_(torch.from_numpy(g[lv0.local_to_global]))
+    rep = pm.AmgSolver(H.operators[0], max_iter=60, rtol=1e-9, global_index=lv0.local_to_global,
+                       n_global=H.part.global_ndofs(orders[0]))
+    xl = pm.Vector(H.layouts[0])
+    out["rep_its"] = rep.solve(xl, bl)
+    A0 = ops[0].assemble_csr()
+    xs = spla.spsolve(A0.tocsc(), g)
+    out["rep_err"] = float(np.abs(xl.data_copy()[: lv0.size_local] - xs[lv0.local_to_global[: lv0.size_local]]).max()
+                           / np.abs(xs).max())
+    out["rep_levels"] = rep.info()
+    reps = pm.AmgSolver(H.operators[0], cycles=8, global_index=lv0.local_to_global,
+                        n_global=H.part.global_ndofs(orders[0]))
+    H.mg.set_coarse_solver(reps)
+    xv.set(0.0)
+    xo = np.zeros_like(b)
+    serr = []
+    for _ in range(2):
+        H.mg.apply(H.rhs[-1], xv)
+        xo = mgo.apply(b, xo)
+        ref = xo[lvf.local_to_global[: lvf.size_local]]
+        serr.append(float(np.abs(xv.data_copy()[: lvf.size_local] - ref).max() / np.abs(xo).max()))
+    out["rep_vcycle_err"] = serr
     H.mg.set_coarse_solver(None)
     return out
 
@@ -169,6 +197,10 @@ def _assert_rank_results(res):
         for e, rn in out["vcycle_err"]:
             assert e < 1e-10 and rn < 1e-8
         assert max(out["amg_vcycle_err"]) < 1e-7, out["amg_vcycle_err"]
+        assert out["rep_err"] < 1e-7 and max(out["rep_vcycle_err"]) < 1e-5, (out["rep_err"], out["rep_vcycle_err"])
+    # the replicated hierarchy is the same on every rank, and it is the single-rank hierarchy
+    assert all(out["rep_its"] == res[0]["rep_its"] and out["rep_levels"] == res[0]["rep_levels"] for out in res)
+    assert res[0]["rep_its"] <= 14
 
 
 def _worker_body(rank, world, port, n, dims, orders):
