@@ -1,4 +1,5 @@
-"""How much does the rank-local AMG hierarchy (a block preconditioner over the ranks) cost in Krylov iterations?
+"""Krylov iterations of the two multi-rank forms of the AMG coarse solver: the rank-local hierarchy (a block
+preconditioner over the ranks) and the replicated one (global matrix gathered on every rank).
 The degree-1 Poisson problem on n^3 cells split over 1, 2, 4, 8 ranks (host threads of one process on one GPU,
 the in-process transport of tests/test_gpu_distributed.py), solved by CG preconditioned by one AMG cycle to
 rtol 1e-8; prints the iteration counts.   usage: python tools/amg_rank_scaling.py [n]"""
@@ -30,11 +31,13 @@ for dims in ((1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2)):
                                          lv.bc_marker, layout)
                 op.compute_diag_inverse()
                 amg = pm.AmgSolver(op, max_iter=200, rtol=1e-8)
+                rep = pm.AmgSolver(op, max_iter=200, rtol=1e-8, global_index=lv.local_to_global,
+                                   n_global=part.global_ndofs(1))
                 g = np.random.default_rng(3).standard_normal(part.global_ndofs(1))[lv.local_to_global]
                 g[lv.bc_marker.astype(bool)] = 0.0
                 b, x = pm.Vector(layout), pm.Vector(layout)
                 b.data.copy_(torch.from_numpy(g))
-                its[rank] = amg.solve(x, b)
+                its[rank] = (amg.solve(x, b), rep.solve(x, b))
                 torch.cuda.current_stream().synchronize()
         except BaseException:
             import traceback
@@ -47,4 +50,5 @@ for dims in ((1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2)):
     if errs:
         print(errs[0])
         sys.exit(1)
-    print(f"{n}^3 cells, {dims[0]}x{dims[1]}x{dims[2]} ranks: CG + rank-local AMG, rtol 1e-8: {its[0]} iterations")
+    print(f"{n}^3 cells, {dims[0]}x{dims[1]}x{dims[2]} ranks, CG + AMG to rtol 1e-8: rank-local hierarchy {its[0][0]} "
+          f"iterations, replicated hierarchy {its[0][1]} iterations")
