@@ -1,0 +1,91 @@
+// One process per GPU and brick: what the reference's drivers get from MPI_Init / mpirun
+// (examples/pmg/submit.sh:29, examples/pmg/select_gpu.sh).  Rank from --rank or RANK /
+// OMPI_COMM_WORLD_RANK / PMI_RANK, the GPU from LOCAL_RANK, the communicator id from rank 0
+// through a file (--id-file); examples/pmg/run_ranks.sh launches the processes.
+#pragma once
+#include "pmg_amd.hpp"
+
+#include <array>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <initializer_list>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <thread>
+
+namespace examples
+{
+struct RankOptions
+{
+  int rank = 0;
+  std::array<int, 3> ranks = {1, 1, 1};
+  bool native_comm = false; // one rank through the RCCL communicator anyway
+  std::string id_file = "/tmp/pmg_amd_comm_id";
+  int size() const { return ranks[0] * ranks[1] * ranks[2]; }
+};
+
+inline int env_int(std::initializer_list<const char*> names, int fallback)
+{
+  for (const char* nm : names)
+    if (const char* v = std::getenv(nm))
+      return std::atoi(v);
+  return fallback;
+}
+
+inline std::array<int, 3> parse3(const char* s)
+{
+  std::array<int, 3> r = {1, 1, 1};
+  if (std::sscanf(s, "%d,%d,%d", &r[0], &r[1], &r[2]) != 3 || r[0] < 1 || r[1] < 1 || r[2] < 1)
+    throw std::runtime_error("expected px,py,pz");
+  return r;
+}
+
+inline int default_rank() { return env_int({"RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK"}, 0); }
+
+/// Select this rank's GPU (before anything else touches the device).
+inline void select_device(const RankOptions& o)
+{
+  if (o.rank < 0 || o.rank >= o.size())
+    throw std::runtime_error("rank out of range for --ranks");
+  int ndev = 0;
+  pmg_amd::hip_check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
+  if (ndev < 1)
+    throw std::runtime_error("no GPU");
+  pmg_amd::hip_check(hipSetDevice(env_int({"LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK"}, o.rank) % ndev), "hipSetDevice");
+}
+
+/// The library's RCCL communicator over all ranks (null on one rank without --native-comm).
+inline std::shared_ptr<const pmg_amd::Communicator> bootstrap(const RankOptions& o)
+{
+  const int size = o.size();
+  if (size == 1 && !o.native_comm)
+    return nullptr;
+  std::array<char, PMG_COMM_ID_BYTES> id{};
+  if (o.rank == 0)
+  {
+    id = pmg_amd::Communicator::unique_id();
+    const std::string tmp = o.id_file + ".tmp";
+    {
+      std::ofstream f(tmp, std::ios::binary);
+      f.write(id.data(), id.size());
+    }
+    std::rename(tmp.c_str(), o.id_file.c_str()); // atomic: readers never see a partial id
+  }
+  else
+  {
+    for (int tries = 0;; ++tries)
+    {
+      std::ifstream f(o.id_file, std::ios::binary);
+      if (f && f.read(id.data(), id.size()))
+        break;
+      if (tries > 600)
+        throw std::runtime_error("timed out waiting for the communicator id in " + o.id_file);
+      std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+  }
+  return std::make_shared<const pmg_amd::Communicator>(o.rank, size, id);
+}
+} // namespace examples

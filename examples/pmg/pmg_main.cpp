@@ -23,6 +23,7 @@
 #define PMG_AMD_DOLFINX_NAMESPACE
 #include "../common/box_mesh.hpp"
 #include "../common/brick_partition.hpp"
+#include "../common/rank_launch.hpp"
 #include "pmg_amd.hpp"
 
 #include <algorithm>
@@ -35,7 +36,6 @@
 #include <iostream>
 #include <random>
 #include <sstream>
-#include <thread>
 #include <tuple>
 
 using namespace dolfinx; // examples/pmg/main.cpp:29
@@ -65,58 +65,14 @@ struct Space
   std::shared_ptr<Element> element() const { return el; }
 };
 
-struct Options
+struct Options : examples::RankOptions
 {
-  int n = 64, cheb_its = 3, cycles = 10, amg_cycles = 0, rank = 0;
-  std::array<int, 3> ranks = {1, 1, 1};
+  int n = 64, cheb_its = 3, cycles = 10, amg_cycles = 0;
   std::vector<int> orders = {1, 2, 4};
-  bool pcg = false, coarse_cg = false, use_amg = false, random_rhs = false, native_comm = false;
-  std::string id_file = "/tmp/pmg_amd_comm_id", output;
+  bool pcg = false, coarse_cg = false, use_amg = false, random_rhs = false;
+  std::string output;
 };
-
-int env_int(std::initializer_list<const char*> names, int fallback)
-{
-  for (const char* nm : names)
-    if (const char* v = std::getenv(nm))
-      return std::atoi(v);
-  return fallback;
-}
-
-std::array<int, 3> parse3(const char* s)
-{
-  std::array<int, 3> r = {1, 1, 1};
-  if (std::sscanf(s, "%d,%d,%d", &r[0], &r[1], &r[2]) != 3 || r[0] < 1 || r[1] < 1 || r[2] < 1)
-    throw std::runtime_error("expected px,py,pz");
-  return r;
-}
-
-std::shared_ptr<const pmg_amd::Communicator> bootstrap(const Options& o, int size)
-{
-  std::array<char, PMG_COMM_ID_BYTES> id{};
-  if (o.rank == 0)
-  {
-    id = pmg_amd::Communicator::unique_id();
-    const std::string tmp = o.id_file + ".tmp";
-    {
-      std::ofstream f(tmp, std::ios::binary);
-      f.write(id.data(), id.size());
-    }
-    std::rename(tmp.c_str(), o.id_file.c_str()); // atomic: readers never see a partial id
-  }
-  else
-  {
-    for (int tries = 0;; ++tries)
-    {
-      std::ifstream f(o.id_file, std::ios::binary);
-      if (f && f.read(id.data(), id.size()))
-        break;
-      if (tries > 600)
-        throw std::runtime_error("timed out waiting for the communicator id in " + o.id_file);
-      std::this_thread::sleep_for(std::chrono::milliseconds(100));
-    }
-  }
-  return std::make_shared<const pmg_amd::Communicator>(o.rank, size, id);
-}
+using examples::parse3;
 
 template <typename FineOperator>
 void solve(const Options& o)
@@ -126,9 +82,7 @@ void solve(const Options& o)
   const std::vector<int>& order = o.orders;
   const T kappa = 2.0; // :190-193
 
-  std::shared_ptr<const pmg_amd::Communicator> comm;
-  if (size > 1 || o.native_comm)
-    comm = bootstrap(o, size);
+  std::shared_ptr<const pmg_amd::Communicator> comm = examples::bootstrap(o);
 
   examples::BrickPartition mesh(o.n, o.ranks, o.rank);
   device_array<T> constants(std::vector<T>(mesh.ncells, kappa));
@@ -366,7 +320,7 @@ int main(int argc, char** argv)
   Options o;
   std::size_t ndofs = 0;
   std::string check_dims;
-  o.rank = env_int({"RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK"}, 0);
+  o.rank = examples::default_rank();
   try
   {
     for (int i = 1; i < argc; ++i)
@@ -441,13 +395,7 @@ int main(int argc, char** argv)
       std::printf("partition %dx%dx%d of %d^3 cells consistent for every degree\n", dims[0], dims[1], dims[2], o.n);
       return 0;
     }
-    if (o.rank < 0 || o.rank >= size)
-      throw std::runtime_error("rank out of range for --ranks");
-    int ndev = 0;
-    hip_check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
-    if (ndev < 1)
-      throw std::runtime_error("no GPU");
-    hip_check(hipSetDevice(env_int({"LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK"}, o.rank) % ndev), "hipSetDevice");
+    examples::select_device(o);
     solve<acc::MatFreeLaplacian<T>>(o);
   }
   catch (const std::exception& ex)

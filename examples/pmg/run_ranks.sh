@@ -1,7 +1,8 @@
 #!/bin/bash
-# Launch pmg_main as one process per GPU and brick (the reference: mpirun -n 8 with
-# ROCR_VISIBLE_DEVICES=$SLURM_LOCALID, examples/pmg/submit.sh:29, select_gpu.sh:2).
-#   usage: run_ranks.sh px,py,pz [pmg_main options ...]
+# Launch a driver (pmg_main by default) as one process per GPU and brick (the reference: mpirun -n 8
+# with ROCR_VISIBLE_DEVICES=$SLURM_LOCALID, examples/pmg/submit.sh:29, select_gpu.sh:2).
+#   usage: run_ranks.sh px,py,pz [driver options ...]
+#          PMG_MAIN=.../bin/cg_main run_ranks.sh 2,2,2 --n 32        (cg_main, vector_update_main)
 # Rank r runs with RANK=r LOCAL_RANK=r; rank 0 publishes the RCCL communicator id in a temporary file.
 set -euo pipefail
 dims=$1; shift

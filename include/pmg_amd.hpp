@@ -866,6 +866,10 @@ namespace acc
 {
 using namespace pmg_amd::acc;
 }
+namespace la
+{
+using Norm = pmg_amd::acc::Norm; // dolfinx::la::Norm::l2 / linf (src/vector.hpp:360-389)
+}
 } // namespace dolfinx
 using pmg_amd::Interpolator;
 #endif

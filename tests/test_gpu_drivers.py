@@ -139,3 +139,65 @@ def test_mat_free_driver_geometry_batching(built):
     (m0,) = grab(r"Geometry tensor held: (\S+) MB", full)
     (m1,) = grab(r"Geometry tensor held: (\S+) MB", bat)
     assert m1 < 0.2 * m0 and "recomputed" in bat
+
+
+def test_cg_driver(built):
+    """examples/cg: Jacobi-CG eigenvalue estimate, then Chebyshev from a non-zero guess on the load
+    vector with a non-zero Dirichlet value (lifting), against the oracle."""
+    from oracle import pmg_oracle as po
+
+    n, P, g_bc = 5, 3, 1.3
+    out = run("cg_main", "--n", n, "--degree", P)
+    mesh = po.BoxMesh(n)
+    marker = mesh.boundary_marker(P)
+    A = po.Laplacian(P, 2.0, mesh.dofmap(P), mesh.xgeom, mesh.geom_dofmap, marker)
+    A0 = po.Laplacian(P, 2.0, mesh.dofmap(P), mesh.xgeom, mesh.geom_dofmap, np.zeros_like(marker))
+    bc = marker.astype(bool)
+
+    cg = po.CGSolver()
+    cg.set_max_iterations(20)
+    cg.set_tolerance(1e-6)
+    cg.store_coefficients(True)
+    its = cg.solve(A, np.zeros(A.ndofs), np.ones(A.ndofs))
+    eig = cg.compute_eigenvalues()
+    (got_its,) = grab(r"Number of iterations (\d+)", out)
+    lo, hi = re.findall(r"Computed eigs = \(([0-9.e+-]+), ([0-9.e+-]+)\)", out)[0]
+    assert int(got_its) == its
+    assert abs(float(lo) - eig[0]) < 1e-8 * eig[-1] and abs(float(hi) - eig[-1]) < 1e-10 * eig[-1]
+
+    c = mesh.dof_coordinates(P)
+    f = 1000 * np.exp(-((c[:, 0] - 0.5) ** 2 + (c[:, 1] - 0.5) ** 2) / 0.02)
+    wdet = A0.w3[None, :] * A0.detJ  # L = inner(f, v) * dx under the GLL rule: lumped mass (no kappa)
+    b = np.bincount(A0.dofmap.ravel(), weights=(wdet * f[A0.dofmap]).ravel(), minlength=A0.ndofs)
+    g = np.where(bc, g_bc, 0.0)
+    b = b - A0.apply(g)  # apply_lifting
+    b[bc] = g_bc  # set_bc
+    (nb,) = grab(r"Norm of b = (\S+)", out)
+    assert abs(nb - np.linalg.norm(b)) < 1e-12 * nb
+
+    x0 = np.where(bc, g_bc, 1.0)
+    got = dict((int(k), float(v)) for k, v in re.findall(r"Chebyshev iteration (\d+): residual norm = (\S+)", out))
+    assert set(got) == {0, 1, 2, 5, 10, 20, 30}
+    for k, rn in sorted(got.items()):
+        x = x0.copy()
+        if k:
+            po.Chebyshev((0.1 * eig[-1], 1.1 * eig[-1]), k).solve(A, x, b)
+        ref = np.linalg.norm(b - A.apply(x))
+        assert abs(rn - ref) < 1e-10 * got[0], (k, rn, ref)
+    (nx,) = grab(r"Norm of x = (\S+)", out)
+    assert abs(nx - np.linalg.norm(x)) < 1e-10 * nx
+
+
+def test_vector_update_driver(built, tmp_path):
+    """examples/vector-update: 100 x {scatter begin; norm; axpy; scatter end}; norms in closed form
+    (x = rank + i on every owned dof); once without and once through the RCCL communicator."""
+    for extra in ([], ["--native-comm", "--id-file", str(tmp_path / "id")]):
+        out = run("vector_update_main", "--ndofs", 20000, *extra)
+        (nd,) = grab(r"Number of dofs-global : (\d+)", out)
+        vals = grab(r"Dot value: (\S+)", out)
+        assert len(vals) == 100
+        for i, v in enumerate(vals):
+            assert abs(v - i * np.sqrt(nd)) < 1e-12 * max(v, 1.0)
+        assert "Ghost check" in out
+        (nx,) = grab(r"Norm of x = (\S+)", out)
+        assert abs(nx - 100 * np.sqrt(nd)) < 1e-10 * nx
