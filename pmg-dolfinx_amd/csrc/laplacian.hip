@@ -344,6 +344,20 @@ __device__ __forceinline__ double2 gload(const double2* p)
     return *p;
 }
 
+// Slice reads.  The compiler pairs neighbouring LDS reads into ds_read2_b64; issued one by one
+// (volatile LDS loads are not paired) the kernel is 7 % faster at P = 5 and 4 % at P = 8, unchanged at
+// P <= 4 and slower at P = 6, 7 (profiles/kernel_tuning_r02.md).
+typedef __attribute__((address_space(3))) volatile double lds_vdouble;
+template <bool UNPAIRED>
+__device__ __forceinline__ double slice_load(double& v)
+{
+  if constexpr (UNPAIRED)
+    return *(lds_vdouble*)&v;
+  else
+    return v;
+}
+constexpr bool unpaired_slice_reads(int P) { return P == 5 || P == 8; }
+
 // minimum waves per SIMD the register allocation has to leave room for: two workgroups per CU up to
 // P = 4; the register-heavy degrees take what they need (profiles/kernel_resources_r02.md)
 template <int P>
@@ -364,6 +378,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   constexpr int MAXM = Sh::MAXM, THREADS = Sh::WTHREADS, ITER = Sh::WITER;
   constexpr int WL = CW * NQ2; // columns of one item (a wave, or WPC waves sharing a cell)
   constexpr bool NT = P >= NT_FROM; // streaming cache policy for G and the y write-back
+  constexpr bool UNPAIRED = unpaired_slice_reads(P);
   __shared__ double sD[ND * ND];
   __shared__ double skap[K];
   __shared__ double sx[MAXM];
@@ -559,8 +574,8 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
 #pragma unroll
       for (int mm = 0; mm < ND; ++mm)
       {
-        qr += Da[mm] * q_s[mm * ND + b];  // d/dx: sum over a, :195-199
-        qs += Db[mm] * q_s[a * ND + mm];  // d/dy: sum over b, :206-210
+        qr += Da[mm] * slice_load<UNPAIRED>(q_s[mm * ND + b]);  // d/dx: sum over a, :195-199
+        qs += Db[mm] * slice_load<UNPAIRED>(q_s[a * ND + mm]);  // d/dy: sum over b, :206-210
         qt += Dg[k * ND + mm] * u[mm];    // d/dz: registers, uniform table, :214-218
       }
       const double fr = kap * (g01.x * qr + g01.y * qs + g23.x * qt); // :233
@@ -573,8 +588,8 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
 #pragma unroll
       for (int mm = 0; mm < ND; ++mm)
       {
-        acc += DTa[mm] * gr_s[mm * ND + b]; // :246-251
-        acc += DTb[mm] * gs_s[a * ND + mm]; // :255-259
+        acc += DTa[mm] * slice_load<UNPAIRED>(gr_s[mm * ND + b]); // :246-251
+        acc += DTb[mm] * slice_load<UNPAIRED>(gs_s[a * ND + mm]); // :255-259
         Aq[mm] += Dg[k * ND + mm] * ft;     // :263-267
       }
       Aq[k] += acc;
