@@ -233,7 +233,7 @@ int pmg_laplacian_set_geometry_batch(pmg_laplacian op, long long batch_cells);
 long long pmg_laplacian_geometry_bytes(pmg_laplacian op);
 /* One operator application issues one stiffness-kernel launch per patch colour of the
  * interior cell list (8 on a structured box) plus one for the boundary list; on a small
- * level -- fewer patch dofs in the interior list than 2 M (degree <= 2) / 6 M (degree >= 3) --
+ * level -- fewer patch dofs in the interior list than 2 M (degree 1) / 6 M (degree >= 2) --
  * the colours are merged into one launch that accumulates with atomics.
  * pmg_set_merge_threshold overrides that limit for operators created afterwards (0: always
  * coloured launches, a huge value: always merged, negative: the defaults above); process-wide,

@@ -333,7 +333,8 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
   // the level is small: eight launches that cannot fill the GPU are launch- and ramp-bound,
   // one launch that adds with atomics is not, as long as the atomics stay few.  Measured
   // (stiffness kernel alone, colours -> merged): P=1 16^3 27 -> 4 us, 64^3 43 -> 23 us;
-  // P=2 32^3 79 -> 13, 48^3 90 -> 47, 64^3 (2.8 M patch dofs) 110 -> 116; P=3 32^3 59 -> 31,
+  // P=2 32^3 79 -> 13, 48^3 90 -> 47, 64^3 (2.8 M patch dofs) 110 -> 116 (whole apply with its zero-fill, timed
+  // in the stream: 110 -> 103), 96^3 (9.5 M) 295 -> 286, 128^3 677 -> 894; P=1 128^3 213 -> 227; P=3 32^3 59 -> 31,
   // 48^3 100 -> 96; P=4 24^3 102 -> 29, 32^3 111 -> 66, 40^3 (5.3 M) 150 -> 126, 48^3 (9.2 M)
   // 206 -> 219, 64^3 427 -> 570; P=6 24^3 141 -> 94; P=8 16^3 174 -> 73.  Hence the
   // thresholds below, in patch dofs (= atomically added values) of the interior list.
@@ -341,7 +342,7 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
     const int nl = ncolours[0];
     const int32_t bfirst = nl < nlaunch ? plan.launch_first[nl] : np;
     const long long interior_pdofs = plan.poff[bfirst];
-    const long long merge_below = g_merge_below >= 0 ? g_merge_below : (long long)(P <= 2 ? 2 : 6) << 20;
+    const long long merge_below = g_merge_below >= 0 ? g_merge_below : (long long)(P <= 1 ? 2 : 6) << 20;
     const bool merge_interior = nl > 1 && interior_pdofs <= merge_below;
     std::vector<int32_t> lf, lc;
     if (merge_interior)
