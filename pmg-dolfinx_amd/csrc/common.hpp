@@ -158,10 +158,12 @@ void launch_pointwise(int n, double* w, const double* x, const double* y, hipStr
 void launch_cheb_init(int n, double* r, double* z, const double* b, const double* q,
                       const double* dinv, double c0, hipStream_t s);
 void launch_cheb_step(int n, double* x, double* r, double* z, const double* q, const double* dinv,
-                      double c1, double c2, hipStream_t s);
+                      double c1, double c2, bool both, bool x_final, hipStream_t s);
+void launch_cheb_residual(int n, double* r, const double* q, hipStream_t s);
 void launch_add(int n, double* x, const double* z, hipStream_t s);
 void launch_cheb_last(int n, double* x, double* r, const double* z, const double* q, bool assign,
                       hipStream_t s);
+void launch_zero(int n, double* x, hipStream_t s);
 void launch_mask_bc(int n, double* b, const int8_t* bc, hipStream_t s);
 // CG fused passes (src/cg.hpp:160-211); alpha = rnorm / *d_py and beta = (*d_new - *d_sub) / rnorm are
 // formed on the device from the reduced scalars, so no host round trip sits between the kernels

@@ -583,7 +583,7 @@ int restrict_patched(pmg_interpolator ip, double* fine, double* coarse, hipStrea
   // ~30 us kernel would cost more than they save.
   const int n_int = interior_patches(ip), n_all = ip->fv.npatch;
   PMG_TRY(pmg_scatter_fwd_begin(ip->lf, fine, (pmg_stream)s));             // :264
-  PMG_HIP(hipMemsetAsync(coarse, 0, sizeof(double) * ip->lc->total(), s)); // :270
+  launch_zero(ip->lc->total(), coarse, s); // :270
   if (n_int > 0)
     PMG_TRY(launch_restrict_patch(ip->ndc, ip->ndf, n_int, ip->pwaves * 64, ip->pshm, s,
                                   make_args(ip, 0), fine, coarse, 1));
@@ -630,7 +630,7 @@ int interp_restrict(pmg_interpolator ip, double* fine, double* coarse, hipStream
     return restrict_patched(ip, fine, coarse, s);
   const size_t shm = sizeof(double) * (ip->ndf * ip->ndc + (size_t)ip->cpb * ip->Nf);
   PMG_TRY(pmg_scatter_fwd_begin(ip->lf, fine, (pmg_stream)s));             // :264
-  PMG_HIP(hipMemsetAsync(coarse, 0, sizeof(double) * ip->lc->total(), s)); // :270
+  launch_zero(ip->lc->total(), coarse, s); // :270
   if (ip->n_l > 0)
     restrict_kernel<<<(ip->n_l + ip->cpb - 1) / ip->cpb, ip->threads, shm, s>>>(
         ip->n_l, ip->lcells, ip->cpb, ip->ndc, ip->ndf, ip->dmc, ip->dmf, ip->M1, ip->inv_mult,

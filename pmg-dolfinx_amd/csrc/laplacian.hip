@@ -897,7 +897,7 @@ int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s)
   // first writer adds with atomics; everything else is stored by its first writer
   const bool zero_all = op->needs_zero || nl == 0 || 2LL * op->n_bzero > l->total();
   if (zero_all)
-    PMG_HIP(hipMemsetAsync(out, 0, sizeof(double) * l->total(), s));
+    launch_zero(l->total(), out, s);
   if (op->n_bzero > 0 && !zero_all)
     zero_list_kernel<<<(op->n_bzero + 255) / 256 > 1024 ? 1024 : (op->n_bzero + 255) / 256, 256, 0, s>>>(
         op->n_bzero, op->bzero, out);

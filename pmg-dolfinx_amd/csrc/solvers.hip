@@ -33,7 +33,7 @@ pmg_layout amg_layout(pmg_amg amg);
 long long amg_capture_state(pmg_amg amg);
 long long laplacian_capture_state(pmg_laplacian op);
 void launch_cheb_first(int n, double* x, double* r, double* z, const double* q, const double* dinv,
-                       double c1, double c2, hipStream_t s);
+                       double c1, double c2, bool x_final, hipStream_t s);
 } // namespace pmg
 
 struct pmg_chebyshev_s
@@ -104,32 +104,41 @@ int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n,
     PMG_TRY(A(x, w.q));                                  // :56
     launch_cheb_init(n, w.r, w.z, b, w.q, dinv, c0, s); // :57,67-68
   }
+  // x absorbs the correction z_{i+1} in the step kernel that computes it (the first step adds z_1 and z_2), so
+  // after the last application only the residual is left to update, and only where it is wanted.
   for (int i = 1; i <= max_iter; ++i)
   {
     const bool last = (i == max_iter);
     if (last && !need_r)
     {
-      if (x_zero && i == 1)
-        PMG_HIP(hipMemcpyAsync(x, w.z, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-      else
-        launch_add(n, x, w.z, s); // :73
+      if (max_iter == 1) // a one-step smoother: z_1 is all there is (:73)
+      {
+        if (x_zero)
+          PMG_HIP(hipMemcpyAsync(x, w.z, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        else
+          launch_add(n, x, w.z, s);
+      }
       break;
     }
     PMG_TRY(A(w.z, w.q)); // :76
     if (last) // need_r: the new z would not be used, only x and r are (:73,77)
     {
-      launch_cheb_last(n, x, w.r, w.z, w.q, x_zero && i == 1, s);
+      if (max_iter == 1)
+        launch_cheb_last(n, x, w.r, w.z, w.q, x_zero, s);
+      else
+        launch_cheb_residual(n, w.r, w.q, s);
       break;
     }
     const double c1 = (2.0 * i - 1.0) / (2.0 * i + 3.0);
     const double c2 = (8.0 * i + 4.0) / (2.0 * i + 3.0) / lmax;
+    const bool x_final = (i + 1 == max_iter); // the last correction enters x here
     if (x_zero && i == 1)
-      launch_cheb_first(n, x, w.r, w.z, w.q, dinv, c1, c2, s);
+      launch_cheb_first(n, x, w.r, w.z, w.q, dinv, c1, c2, x_final, s);
     else
-      launch_cheb_step(n, x, w.r, w.z, w.q, dinv, c1, c2, s); // :73,77,80-83
+      launch_cheb_step(n, x, w.r, w.z, w.q, dinv, c1, c2, i == 1, x_final, s); // :73,77,80-83
   }
   if (max_iter == 0 && x_zero)
-    PMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * n, s));
+    launch_zero(n, x, s);
   PMG_HIP(hipGetLastError());
   return PMG_OK;
 }
@@ -195,7 +204,7 @@ int mg_apply(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStr
       PMG_TRY(amg_solve(mg->coarse_amg, mg->u[0], mg->b[0], s));
     else if ((mg->coarse || mg->coarse_fn) && L > 1) // :106-107, KSP-style: zero initial guess
     {
-      PMG_HIP(hipMemsetAsync(mg->u[0], 0, sizeof(double) * mg->layouts[0]->total(), s));
+      launch_zero(mg->layouts[0]->total(), mg->u[0], s);
       if (mg->coarse_fn)
       {
         if (mg->coarse_fn(mg->coarse_user, mg->u[0], mg->b[0], (pmg_stream)s) != 0)

@@ -193,71 +193,106 @@ struct ChebInitF
     z[i] = c0 * dinv[i] * vr;
   }
 };
-template <bool NT>
+// The iterate absorbs every correction z_{i+1} in the kernel that computes it (x is streamed by that
+// kernel anyway), so no pass is needed for "x += z" after the last operator application:
+//   step 1:      x = (x + z_1) + z_2   (the sums in the order of src/chebyshev.hpp:73)
+//   step i >= 2: x += z_{i+1}
+template <bool NT, bool BOTH>
 struct ChebStepF
-{ // x += z ; r -= q ; z = c1 z + c2 dinv r   (src/chebyshev.hpp:73-83)
+{ // r -= q ; z_new = c1 z + c2 dinv r ; x += (z if BOTH) + z_new   (src/chebyshev.hpp:73-83)
   double* x;
   double* r;
   double* z;
   const double* q;
   const double* dinv;
   double c1, c2;
+  int x_final; // the last correction: x is gathered next (apply / prolongation), keep it in cache
   __device__ void pair(int i) const
   {
     double2 vx = ld2<NT>(x, i), vr = ld2<NT>(r, i), vz = D2(z)[i];
     double2 vq = ld2<NT>(q, i), vd = ld2<NT>(dinv, i);
-    vx.x += vz.x;
-    vx.y += vz.y;
+    if constexpr (BOTH)
+    {
+      vx.x += vz.x;
+      vx.y += vz.y;
+    }
     vr.x -= vq.x;
     vr.y -= vq.y;
     vz.x = c1 * vz.x + c2 * vd.x * vr.x;
     vz.y = c1 * vz.y + c2 * vd.y * vr.y;
-    st2<NT>(x, i, vx);
+    vx.x += vz.x;
+    vx.y += vz.y;
+    if (x_final)
+      D2(x)[i] = vx;
+    else
+      st2<NT>(x, i, vx);
     st2<NT>(r, i, vr);
     D2(z)[i] = vz;
   }
   __device__ void one(int i) const
   {
-    double vz = z[i];
-    x[i] += vz;
+    double vz = z[i], vx = x[i];
+    if constexpr (BOTH)
+      vx += vz;
     double vr = r[i] - q[i];
     r[i] = vr;
-    z[i] = c1 * vz + c2 * dinv[i] * vr;
+    vz = c1 * vz + c2 * dinv[i] * vr;
+    z[i] = vz;
+    x[i] = vx + vz;
   }
 };
 template <bool NT>
 struct ChebFirstF
-{ // first step from x == 0:  x = z ; r -= q ; z = c1 z + c2 dinv r
+{ // first step from x == 0:  r -= q ; z_2 = c1 z_1 + c2 dinv r ; x = z_1 + z_2
   double* x;
   double* r;
   double* z;
   const double* q;
   const double* dinv;
   double c1, c2;
+  int x_final;
   __device__ void pair(int i) const
   {
     double2 vr = ld2<NT>(r, i), vz = D2(z)[i];
     double2 vq = ld2<NT>(q, i), vd = ld2<NT>(dinv, i);
-    st2<NT>(x, i, vz);
+    double2 vx = vz;
     vr.x -= vq.x;
     vr.y -= vq.y;
     vz.x = c1 * vz.x + c2 * vd.x * vr.x;
     vz.y = c1 * vz.y + c2 * vd.y * vr.y;
+    if (x_final)
+      D2(x)[i] = make_double2(vx.x + vz.x, vx.y + vz.y);
+    else
+      st2<NT>(x, i, make_double2(vx.x + vz.x, vx.y + vz.y));
     st2<NT>(r, i, vr);
     D2(z)[i] = vz;
   }
   __device__ void one(int i) const
   {
     double vz = z[i];
-    x[i] = vz;
+    const double vx = vz;
     double vr = r[i] - q[i];
     r[i] = vr;
-    z[i] = c1 * vz + c2 * dinv[i] * vr;
+    vz = c1 * vz + c2 * dinv[i] * vr;
+    z[i] = vz;
+    x[i] = vx + vz;
   }
 };
 template <bool NT>
+struct ChebResidualF
+{ // after the last application when the residual is wanted: r -= q   (src/chebyshev.hpp:77)
+  double* r;
+  const double* q;
+  __device__ void pair(int i) const
+  {
+    double2 vr = ld2<NT>(r, i), vq = ld2<NT>(q, i);
+    D2(r)[i] = make_double2(vr.x - vq.x, vr.y - vq.y); // r is gathered next (restriction)
+  }
+  __device__ void one(int i) const { r[i] -= q[i]; }
+};
+template <bool NT>
 struct ChebLastF
-{ // last step when only x and the residual are wanted:  x (+)= z ; r -= q
+{ // the only step of a one-step smoother when x and the residual are wanted:  x (+)= z ; r -= q
   double* x;
   double* r;
   const double* z;
@@ -480,22 +515,38 @@ void launch_cheb_init(int n, double* r, double* z, const double* b, const double
     ew_launch(n, v, ChebInitF<false>{r, z, b, q, dinv, c0}, s);
 }
 void launch_cheb_step(int n, double* x, double* r, double* z, const double* q, const double* dinv,
-                      double c1, double c2, hipStream_t s)
+                      double c1, double c2, bool both, bool x_final, hipStream_t s)
 {
+  const int xf = x_final ? 1 : 0;
   bool v = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(q) && aligned16(dinv);
   if (streams(n))
-    ew_launch(n, v, ChebStepF<true>{x, r, z, q, dinv, c1, c2}, s);
+  {
+    if (both)
+      ew_launch(n, v, ChebStepF<true, true>{x, r, z, q, dinv, c1, c2, xf}, s);
+    else
+      ew_launch(n, v, ChebStepF<true, false>{x, r, z, q, dinv, c1, c2, xf}, s);
+  }
+  else if (both)
+    ew_launch(n, v, ChebStepF<false, true>{x, r, z, q, dinv, c1, c2, xf}, s);
   else
-    ew_launch(n, v, ChebStepF<false>{x, r, z, q, dinv, c1, c2}, s);
+    ew_launch(n, v, ChebStepF<false, false>{x, r, z, q, dinv, c1, c2, xf}, s);
+}
+void launch_cheb_residual(int n, double* r, const double* q, hipStream_t s)
+{
+  if (streams(n))
+    ew_launch(n, aligned16(r) && aligned16(q), ChebResidualF<true>{r, q}, s);
+  else
+    ew_launch(n, aligned16(r) && aligned16(q), ChebResidualF<false>{r, q}, s);
 }
 void launch_cheb_first(int n, double* x, double* r, double* z, const double* q, const double* dinv,
-                       double c1, double c2, hipStream_t s)
+                       double c1, double c2, bool x_final, hipStream_t s)
 {
   bool v = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(q) && aligned16(dinv);
+  const int xf = x_final ? 1 : 0;
   if (streams(n))
-    ew_launch(n, v, ChebFirstF<true>{x, r, z, q, dinv, c1, c2}, s);
+    ew_launch(n, v, ChebFirstF<true>{x, r, z, q, dinv, c1, c2, xf}, s);
   else
-    ew_launch(n, v, ChebFirstF<false>{x, r, z, q, dinv, c1, c2}, s);
+    ew_launch(n, v, ChebFirstF<false>{x, r, z, q, dinv, c1, c2, xf}, s);
 }
 void launch_cheb_last(int n, double* x, double* r, const double* z, const double* q, bool assign,
                       hipStream_t s)
@@ -513,6 +564,8 @@ void launch_add(int n, double* x, const double* z, hipStream_t s)
   else
     ew_launch(n, aligned16(x) && aligned16(z), AddF<false>{x, z}, s);
 }
+// x[0..n) = 0 in ONE kernel (hipMemsetAsync issues two, ~5 us apiece on a small level)
+void launch_zero(int n, double* x, hipStream_t s) { ew_launch(n, aligned16(x), SetF{x, 0.0}, s); }
 void launch_mask_bc(int n, double* b, const int8_t* bc, hipStream_t s)
 {
   ew_launch(n, true, MaskBcF{b, bc}, s);
