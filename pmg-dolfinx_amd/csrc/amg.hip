@@ -532,16 +532,16 @@ int amg_cycle(pmg_amg amg, int l, double* x, const double* b, hipStream_t s)
     const ChebWork w{lv.r, lv.z, lv.q};
     return cheb_iterate(
         w, [&lv, s](double* in, double* out) { return csr_product<0>(lv.A, in, nullptr, out, s); }, lv.dinv, lv.n,
-        lv.lmax, 4 * amg->smoother_its, x, b, false, true, s);
+        lv.lmax, 4 * amg->smoother_its, x, b, ResidualNone, true, s);
   }
   const ChebWork w{lv.r, lv.z, lv.q};
   const ApplyFn A = [&lv, s](double* in, double* out) { return csr_product<0>(lv.A, in, nullptr, out, s); };
   AmgLevel& lc = amg->levels[l + 1];
-  PMG_TRY(cheb_iterate(w, A, lv.dinv, lv.n, lv.lmax, amg->smoother_its, x, b, true, true, s)); // leaves r = b - A x
+  PMG_TRY(cheb_iterate(w, A, lv.dinv, lv.n, lv.lmax, amg->smoother_its, x, b, ResidualUpdated, true, s)); // leaves r = b - A x
   PMG_TRY(csr_product<0>(lv.R, lv.r, nullptr, lc.b, s));
   PMG_TRY(amg_cycle(amg, l + 1, lc.x, lc.b, s));
   PMG_TRY(csr_product<2>(lv.P, lc.x, nullptr, x, s)); // x += P x_c
-  PMG_TRY(cheb_iterate(w, A, lv.dinv, lv.n, lv.lmax, amg->smoother_its, x, b, false, false, s));
+  PMG_TRY(cheb_iterate(w, A, lv.dinv, lv.n, lv.lmax, amg->smoother_its, x, b, ResidualNone, false, s));
   return PMG_OK;
 }
 } // namespace

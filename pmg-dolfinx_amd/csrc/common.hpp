@@ -140,8 +140,14 @@ using ApplyFn = std::function<int(double* in, double* out)>;
 using PrecondFn = std::function<int(double* z, const double* r)>;
 int cg_iterate(pmg_cg cg, const ApplyFn& A, const double* dinv, const PrecondFn* M, bool flexible, double* x,
                const double* b, int* iterations, hipStream_t s);
+enum : int
+{
+  ResidualNone = 0,    // only x is wanted
+  ResidualUpdated = 1, // w.r = b - A x on return
+  ResidualSplit = 2    // b - A x = w.r - w.q is left to the consumer when *split comes back true
+};
 int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n, double lmax, int max_iter,
-                 double* x, const double* b, bool need_r, bool x_zero, hipStream_t s);
+                 double* x, const double* b, int need_r, bool x_zero, hipStream_t s, bool* split = nullptr);
 
 // vector.hip -- stream-ordered building blocks used by the solvers
 // local dot of the owned entries into the result slot `slot` of the layout (device)

@@ -317,7 +317,8 @@ __global__ void prolong_patch_kernel(TransferArgs A, const double* __restrict__ 
 
 template <int NDC, int NDF>
 __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__ fine,
-                                      double* __restrict__ coarse, int atomic_out)
+                                      const double* __restrict__ fine_sub, double* __restrict__ coarse,
+                                      int atomic_out)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int ndc = NDC, ndf = NDF, Nc = ndc * ndc * ndc, Nf = ndf * ndf * ndf;
@@ -350,6 +351,12 @@ __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       v[k] = A.nt ? __builtin_nontemporal_load(fine + (m[k] & PD_MASK)) : fine[m[k] & PD_MASK];
+    if (fine_sub) // the residual r - q formed here instead of in a pass of its own (src/chebyshev.hpp:77)
+    {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        v[k] -= A.nt ? __builtin_nontemporal_load(fine_sub + (m[k] & PD_MASK)) : fine_sub[m[k] & PD_MASK];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
@@ -475,12 +482,13 @@ int launch_prolong_patch(int ndc, int ndf, int grid, int threads, size_t shm, hi
 }
 
 int launch_restrict_patch(int ndc, int ndf, int grid, int threads, size_t shm, hipStream_t s,
-                          const TransferArgs& A, const double* fine, double* coarse, int atomic_out)
+                          const TransferArgs& A, const double* fine, const double* fine_sub, double* coarse,
+                          int atomic_out)
 {
 #define X(C, F)                                                                                    \
   if (ndc == C && ndf == F)                                                                        \
   {                                                                                                \
-    restrict_patch_kernel<C, F><<<grid, threads, shm, s>>>(A, fine, coarse, atomic_out);           \
+    restrict_patch_kernel<C, F><<<grid, threads, shm, s>>>(A, fine, fine_sub, coarse, atomic_out); \
     return PMG_OK;                                                                                 \
   }
   PMG_FOR_PAIRS(X)
@@ -574,23 +582,25 @@ int prolong_patched(pmg_interpolator ip, double* coarse, double* fine, int add, 
   return PMG_OK;
 }
 
-int restrict_patched(pmg_interpolator ip, double* fine, double* coarse, hipStream_t s)
+int restrict_patched(pmg_interpolator ip, double* fine, const double* fine_sub, double* coarse, hipStream_t s)
 {
   // One launch per cell list; the patch sums go to the (small) coarse vector with
   // FP64 atomics: a patch issues a few dozen 64-byte atomic requests (its coarse
   // dofs form long runs), three orders of magnitude fewer than one per
   // (cell, coarse dof) as in src/interpolate.hpp:84, and 8 colour launches of a
   // ~30 us kernel would cost more than they save.
+  // fine_sub (optional, layouts without ghosts only): restrict fine - fine_sub.
   const int n_int = interior_patches(ip), n_all = ip->fv.npatch;
+  PMG_REQUIRE(!fine_sub || ip->lf->num_ghosts == 0, "restriction of a difference needs a layout without ghosts");
   PMG_TRY(pmg_scatter_fwd_begin(ip->lf, fine, (pmg_stream)s));             // :264
   launch_zero(ip->lc->total(), coarse, s); // :270
   if (n_int > 0)
     PMG_TRY(launch_restrict_patch(ip->ndc, ip->ndf, n_int, ip->pwaves * 64, ip->pshm, s,
-                                  make_args(ip, 0), fine, coarse, 1));
+                                  make_args(ip, 0), fine, fine_sub, coarse, 1));
   PMG_TRY(pmg_scatter_fwd_end(ip->lf, fine, (pmg_stream)s)); // :281
   if (n_all > n_int)
     PMG_TRY(launch_restrict_patch(ip->ndc, ip->ndf, n_all - n_int, ip->pwaves * 64, ip->pshm, s,
-                                  make_args(ip, n_int), fine, coarse, 1));
+                                  make_args(ip, n_int), fine, fine_sub, coarse, 1));
   PMG_HIP(hipGetLastError());
   return PMG_OK;
 }
@@ -605,6 +615,17 @@ int interp_prolong_add(pmg_interpolator ip, double* coarse, double* fine, hipStr
 {
   PMG_REQUIRE(ip->patched, "interp_prolong_add needs the patch path");
   return prolong_patched(ip, coarse, fine, 1, s);
+}
+
+// can the restriction form the residual r - q itself?  (patch path, no halo to refresh)
+bool interp_restricts_difference(pmg_interpolator ip) { return ip->patched && ip->lf->num_ghosts == 0; }
+
+// coarse = R (fine - fine_sub)
+int interp_restrict_difference(pmg_interpolator ip, double* fine, const double* fine_sub, double* coarse,
+                               hipStream_t s)
+{
+  PMG_REQUIRE(interp_restricts_difference(ip), "interp_restrict_difference: not available for this interpolator");
+  return restrict_patched(ip, fine, fine_sub, coarse, s);
 }
 
 int interp_prolong(pmg_interpolator ip, double* coarse, double* fine, hipStream_t s)
@@ -627,7 +648,7 @@ int interp_prolong(pmg_interpolator ip, double* coarse, double* fine, hipStream_
 int interp_restrict(pmg_interpolator ip, double* fine, double* coarse, hipStream_t s)
 {
   if (ip->patched)
-    return restrict_patched(ip, fine, coarse, s);
+    return restrict_patched(ip, fine, nullptr, coarse, s);
   const size_t shm = sizeof(double) * (ip->ndf * ip->ndc + (size_t)ip->cpb * ip->Nf);
   PMG_TRY(pmg_scatter_fwd_begin(ip->lf, fine, (pmg_stream)s));             // :264
   launch_zero(ip->lc->total(), coarse, s); // :270

@@ -28,6 +28,9 @@ int interp_prolong(pmg_interpolator ip, double* coarse, double* fine, hipStream_
 int interp_restrict(pmg_interpolator ip, double* fine, double* coarse, hipStream_t s);
 int interp_prolong_add(pmg_interpolator ip, double* coarse, double* fine, hipStream_t s);
 bool interp_is_patched(pmg_interpolator ip);
+bool interp_restricts_difference(pmg_interpolator ip);
+int interp_restrict_difference(pmg_interpolator ip, double* fine, const double* fine_sub, double* coarse,
+                               hipStream_t s);
 int amg_solve(pmg_amg amg, double* x, const double* b, hipStream_t s);
 pmg_layout amg_layout(pmg_amg amg);
 long long amg_capture_state(pmg_amg amg);
@@ -93,9 +96,15 @@ namespace pmg
 // src/chebyshev.hpp:46-91.
 //   need_r : keep r = b - A x current on exit (costs the loop's last apply)
 //   x_zero : x is known to be 0 on entry (A 0 = 0, so r = b and x := z)
+// need_r: ResidualNone -- only x is wanted; ResidualUpdated -- w.r holds b - A x on return;
+// ResidualSplit -- the caller forms it: b - A x = w.r - w.q (the consumer, a restriction, subtracts while it gathers;
+// falls back to ResidualUpdated for a one-step smoother, whose last kernel updates x and r together).
+// Returns through *split whether the pair was left.
 int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n, double lmax, int max_iter,
-                 double* x, const double* b, bool need_r, bool x_zero, hipStream_t s)
+                 double* x, const double* b, int need_r, bool x_zero, hipStream_t s, bool* split)
 {
+  if (split)
+    *split = false;
   const double c0 = 4.0 / (3.0 * lmax);
   if (x_zero)
     launch_cheb_init(n, w.r, w.z, b, nullptr, dinv, c0, s);
@@ -125,6 +134,8 @@ int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n,
     {
       if (max_iter == 1)
         launch_cheb_last(n, x, w.r, w.z, w.q, x_zero, s);
+      else if (need_r == ResidualSplit && split)
+        *split = true;
       else
         launch_cheb_residual(n, w.r, w.q, s);
       break;
@@ -157,8 +168,8 @@ int alloc_vec(pmg_layout l, double** p)
 }
 
 // src/chebyshev.hpp:46-91 on the operator `A` (see cheb_iterate)
-int cheb_solve(pmg_chebyshev sm, pmg_laplacian A, double* x, const double* b, bool need_r,
-               bool x_zero, hipStream_t s)
+int cheb_solve(pmg_chebyshev sm, pmg_laplacian A, double* x, const double* b, int need_r,
+               bool x_zero, hipStream_t s, bool* split = nullptr)
 {
   pmg_layout l = sm->layout;
   PMG_REQUIRE(laplacian_layout(A) == l, "Chebyshev: operator and smoother layouts differ");
@@ -166,7 +177,7 @@ int cheb_solve(pmg_chebyshev sm, pmg_laplacian A, double* x, const double* b, bo
   // eig_range[0] is unused (src/chebyshev.hpp:51); no per-call D2D copy of the diagonal (:53)
   return cheb_iterate(
       w, [A, s](double* in, double* out) { return laplacian_apply(A, in, out, s); }, laplacian_diag_inv(A),
-      l->size_local, sm->eig_max, sm->max_iter, x, b, need_r, x_zero, s);
+      l->size_local, sm->eig_max, sm->max_iter, x, b, need_r, x_zero, s, split);
 }
 
 // src/pmg.hpp:56-155 (lean form, see the file header)
@@ -187,12 +198,19 @@ int mg_apply(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStr
   {
     const double* bi = (i == L - 1) ? rhs : mg->b[i];
     const bool zero = (i == L - 1) ? y_zero : true;
+    bool split = false;
     {
       Range rg("pmg:pre_smooth");
-      PMG_TRY(cheb_solve(mg->smoothers[i], mg->ops[i], mg->u[i], bi, true, zero, s)); // :83-87
+      PMG_TRY(cheb_solve(mg->smoothers[i], mg->ops[i], mg->u[i], bi,
+                         interp_restricts_difference(mg->interps[i - 1]) ? ResidualSplit : ResidualUpdated, zero, s,
+                         &split)); // :83-87
     }
     Range rg("pmg:restrict");
-    PMG_TRY(interp_restrict(mg->interps[i - 1], mg->smoothers[i]->r, mg->b[i - 1], s)); // :92
+    if (split) // the residual r - q is formed by the restriction's gather
+      PMG_TRY(interp_restrict_difference(mg->interps[i - 1], mg->smoothers[i]->r, mg->smoothers[i]->q,
+                                         mg->b[i - 1], s));
+    else
+      PMG_TRY(interp_restrict(mg->interps[i - 1], mg->smoothers[i]->r, mg->b[i - 1], s)); // :92
   }
   if (L > 1)
     launch_mask_bc(mg->layouts[0]->size_local, mg->b[0], mg->bc0, s); // :100-103
@@ -217,7 +235,7 @@ int mg_apply(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStr
       }
     }
     else
-      PMG_TRY(cheb_solve(mg->smoothers[0], mg->ops[0], mg->u[0], b0, false, zero, s)); // :109
+      PMG_TRY(cheb_solve(mg->smoothers[0], mg->ops[0], mg->u[0], b0, ResidualNone, zero, s)); // :109
   }
   for (int i = 0; i < L - 1; ++i)
   {
@@ -234,7 +252,7 @@ int mg_apply(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStr
     }
     Range rg("pmg:post_smooth");
     const double* bi = (i + 1 == L - 1) ? rhs : mg->b[i + 1];
-    PMG_TRY(cheb_solve(mg->smoothers[i + 1], mg->ops[i + 1], mg->u[i + 1], bi, false, false, s)); // :138
+    PMG_TRY(cheb_solve(mg->smoothers[i + 1], mg->ops[i + 1], mg->u[i + 1], bi, ResidualNone, false, s)); // :138
   }
   for (int i = 0; i < L; ++i)
     mg->counts[i] = (int)(laplacian_launches(mg->ops[i]) - before[i]);
@@ -283,7 +301,7 @@ extern "C" int pmg_chebyshev_solve(pmg_chebyshev sm, pmg_laplacian A, double* x,
                                    pmg_stream stream)
 {
   PMG_REQUIRE(sm && A && x && b, "pmg_chebyshev_solve: NULL argument");
-  return cheb_solve(sm, A, x, b, false, false, S(stream));
+  return cheb_solve(sm, A, x, b, ResidualNone, false, S(stream));
 }
 
 // -------------------------------------------------------------------- CG --
