@@ -4,8 +4,9 @@
 // synchronisations are the CG dot products (their values steer the iteration,
 // src/cg.hpp:182,195,206) and an optional residual norm of the V-cycle.
 //
-// The smoother issues one fused vector pass per Chebyshev step (x += z; r -= q;
-// z = c1 z + c2 D^-1 r : 5 reads + 3 writes per dof) where the reference issues
+// The smoother issues one fused vector pass per Chebyshev step (r -= q;
+// z = c1 z + c2 D^-1 r; x += z : 5 reads + 3 writes per dof; x takes each correction in
+// the pass that computes it, so no pass follows the last apply) where the reference issues
 // 5 Thrust launches (src/chebyshev.hpp:73-83), and the V-cycle drops the residual
 // recomputations that only feed log lines (src/pmg.hpp:76-89,114-117,132-143):
 // the residual a pre-smooth leaves in its recurrence IS b - A u (:86-87), and the
@@ -94,12 +95,12 @@ struct pmg_multigrid_s
 namespace pmg
 {
 // src/chebyshev.hpp:46-91.
-//   need_r : keep r = b - A x current on exit (costs the loop's last apply)
 //   x_zero : x is known to be 0 on entry (A 0 = 0, so r = b and x := z)
-// need_r: ResidualNone -- only x is wanted; ResidualUpdated -- w.r holds b - A x on return;
-// ResidualSplit -- the caller forms it: b - A x = w.r - w.q (the consumer, a restriction, subtracts while it gathers;
-// falls back to ResidualUpdated for a one-step smoother, whose last kernel updates x and r together).
-// Returns through *split whether the pair was left.
+//   need_r : ResidualNone    -- only x is wanted: the loop's last apply is skipped;
+//            ResidualUpdated -- w.r = b - A x on return (costs that last apply);
+//            ResidualSplit   -- as ResidualUpdated, but the last "r -= q" is left to the consumer when *split
+//                               comes back true: b - A x = w.r - w.q (a restriction subtracts while it gathers; a
+//                               one-step smoother, whose only kernel updates x and r together, returns false).
 int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n, double lmax, int max_iter,
                  double* x, const double* b, int need_r, bool x_zero, hipStream_t s, bool* split)
 {
