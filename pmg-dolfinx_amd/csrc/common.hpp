@@ -146,8 +146,12 @@ enum : int
   ResidualUpdated = 1, // w.r = b - A x on return
   ResidualSplit = 2    // b - A x = w.r - w.q is left to the consumer when *split comes back true
 };
+// A_zeroed (optional): the same operator for an output vector that is already zero over [0, n_total) -- given for
+// an operator whose launch accumulates with atomics; the smoother's vector kernels then clear w.q behind themselves
+// and every application after the first goes through A_zeroed (no zero-fill kernels).
 int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n, double lmax, int max_iter,
-                 double* x, const double* b, int need_r, bool x_zero, hipStream_t s, bool* split = nullptr);
+                 double* x, const double* b, int need_r, bool x_zero, hipStream_t s, bool* split = nullptr,
+                 const ApplyFn* A_zeroed = nullptr, int n_total = 0);
 
 // vector.hip -- stream-ordered building blocks used by the solvers
 // local dot of the owned entries into the result slot `slot` of the layout (device)
@@ -161,10 +165,12 @@ int dot_host(pmg_layout l, const double* a, const double* b, double* result, hip
 void launch_axpy(int n, double* r, double alpha, const double* x, const double* y, hipStream_t s);
 void launch_pointwise(int n, double* w, const double* x, const double* y, hipStream_t s);
 // Chebyshev fused passes (src/chebyshev.hpp:57-83)
+// clear_q (optional): the operator's output, zeroed over [0, n_total) behind the update (see ThenClearF)
 void launch_cheb_init(int n, double* r, double* z, const double* b, const double* q,
-                      const double* dinv, double c0, hipStream_t s);
+                      const double* dinv, double c0, hipStream_t s, double* clear_q = nullptr, int n_total = 0);
 void launch_cheb_step(int n, double* x, double* r, double* z, const double* q, const double* dinv,
-                      double c1, double c2, bool both, bool x_final, hipStream_t s);
+                      double c1, double c2, bool both, bool x_final, hipStream_t s, double* clear_q = nullptr,
+                      int n_total = 0);
 void launch_cheb_residual(int n, double* r, const double* q, hipStream_t s);
 void launch_add(int n, double* x, const double* z, hipStream_t s);
 void launch_cheb_last(int n, double* x, double* r, const double* z, const double* q, bool assign,

@@ -844,6 +844,7 @@ namespace pmg
 {
 // used by solvers.hip
 int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s);
+int laplacian_apply_zeroed(pmg_laplacian op, double* in, double* out, hipStream_t s);
 const double* laplacian_diag_inv(pmg_laplacian op) { return op->diag_inv; }
 pmg_layout laplacian_layout(pmg_laplacian op) { return op->layout; }
 long long laplacian_launches(pmg_laplacian op) { return op->applies; }
@@ -888,15 +889,24 @@ PatchView laplacian_patches(pmg_laplacian op)
   return v;
 }
 
+// Does an application zero-fill its whole output first (every first writer adds with atomics: the merged launch of a
+// small level)?  Then a caller that hands over an output that is zero already can skip the fill
+// (laplacian_apply_zeroed; the smoother's vector kernels clear the vector behind themselves).
+static bool zero_fills_output(pmg_laplacian op)
+{
+  return op->needs_zero || op->launch_first.empty() || 2LL * op->n_bzero > op->layout->total();
+}
+bool laplacian_wants_zeroed_output(pmg_laplacian op) { return zero_fills_output(op); }
+
 // operator()(in, out), src/laplacian.hpp:462-482 + impl_operator :373-460
-int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s)
+static int apply_impl(pmg_laplacian op, double* in, double* out, bool out_is_zero, hipStream_t s)
 {
   pmg_layout l = op->layout;
   const int nl = (int)op->launch_first.size();
   // :466 -- but only where needed: dofs no patch touches, or (most of the vector) dofs whose
   // first writer adds with atomics; everything else is stored by its first writer
-  const bool zero_all = op->needs_zero || nl == 0 || 2LL * op->n_bzero > l->total();
-  if (zero_all)
+  const bool zero_all = zero_fills_output(op);
+  if (zero_all && !out_is_zero)
     launch_zero(l->total(), out, s);
   if (op->n_bzero > 0 && !zero_all)
     zero_list_kernel<<<(op->n_bzero + 255) / 256 > 1024 ? 1024 : (op->n_bzero + 255) / 256, 256, 0, s>>>(
@@ -907,6 +917,12 @@ int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s)
   PMG_TRY(run_launches(op, in, out, op->n_launch_l, nl, s));     // :429-455 boundary cells
   op->applies++;
   return PMG_OK;
+}
+int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s) { return apply_impl(op, in, out, false, s); }
+// `out` is zero over the whole layout already (only meaningful when laplacian_wants_zeroed_output)
+int laplacian_apply_zeroed(pmg_laplacian op, double* in, double* out, hipStream_t s)
+{
+  return apply_impl(op, in, out, zero_fills_output(op), s);
 }
 } // namespace pmg
 

@@ -37,7 +37,9 @@ pmg_layout amg_layout(pmg_amg amg);
 long long amg_capture_state(pmg_amg amg);
 long long laplacian_capture_state(pmg_laplacian op);
 void launch_cheb_first(int n, double* x, double* r, double* z, const double* q, const double* dinv,
-                       double c1, double c2, bool x_final, hipStream_t s);
+                       double c1, double c2, bool x_final, hipStream_t s, double* clear_q = nullptr, int n_total = 0);
+bool laplacian_wants_zeroed_output(pmg_laplacian op);
+int laplacian_apply_zeroed(pmg_laplacian op, double* in, double* out, hipStream_t s);
 } // namespace pmg
 
 struct pmg_chebyshev_s
@@ -102,17 +104,20 @@ namespace pmg
 //                               comes back true: b - A x = w.r - w.q (a restriction subtracts while it gathers; a
 //                               one-step smoother, whose only kernel updates x and r together, returns false).
 int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n, double lmax, int max_iter,
-                 double* x, const double* b, int need_r, bool x_zero, hipStream_t s, bool* split)
+                 double* x, const double* b, int need_r, bool x_zero, hipStream_t s, bool* split,
+                 const ApplyFn* A_zeroed, int n_total)
 {
   if (split)
     *split = false;
+  double* const clear_q = A_zeroed ? w.q : nullptr; // the vector kernels leave w.q zero for the next application
+  const ApplyFn& An = A_zeroed ? *A_zeroed : A;    // ... which then needs no zero-fill
   const double c0 = 4.0 / (3.0 * lmax);
   if (x_zero)
-    launch_cheb_init(n, w.r, w.z, b, nullptr, dinv, c0, s);
+    launch_cheb_init(n, w.r, w.z, b, nullptr, dinv, c0, s, clear_q, n_total);
   else
   {
-    PMG_TRY(A(x, w.q));                                  // :56
-    launch_cheb_init(n, w.r, w.z, b, w.q, dinv, c0, s); // :57,67-68
+    PMG_TRY(A(x, w.q));                                                     // :56
+    launch_cheb_init(n, w.r, w.z, b, w.q, dinv, c0, s, clear_q, n_total); // :57,67-68
   }
   // x absorbs the correction z_{i+1} in the step kernel that computes it (the first step adds z_1 and z_2), so
   // after the last application only the residual is left to update, and only where it is wanted.
@@ -130,7 +135,7 @@ int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n,
       }
       break;
     }
-    PMG_TRY(A(w.z, w.q)); // :76
+    PMG_TRY(An(w.z, w.q)); // :76
     if (last) // need_r: the new z would not be used, only x and r are (:73,77)
     {
       if (max_iter == 1)
@@ -145,9 +150,9 @@ int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n,
     const double c2 = (8.0 * i + 4.0) / (2.0 * i + 3.0) / lmax;
     const bool x_final = (i + 1 == max_iter); // the last correction enters x here
     if (x_zero && i == 1)
-      launch_cheb_first(n, x, w.r, w.z, w.q, dinv, c1, c2, x_final, s);
+      launch_cheb_first(n, x, w.r, w.z, w.q, dinv, c1, c2, x_final, s, clear_q, n_total);
     else
-      launch_cheb_step(n, x, w.r, w.z, w.q, dinv, c1, c2, i == 1, x_final, s); // :73,77,80-83
+      launch_cheb_step(n, x, w.r, w.z, w.q, dinv, c1, c2, i == 1, x_final, s, clear_q, n_total); // :73,77,80-83
   }
   if (max_iter == 0 && x_zero)
     launch_zero(n, x, s);
@@ -176,9 +181,10 @@ int cheb_solve(pmg_chebyshev sm, pmg_laplacian A, double* x, const double* b, in
   PMG_REQUIRE(laplacian_layout(A) == l, "Chebyshev: operator and smoother layouts differ");
   const ChebWork w{sm->r, sm->z, sm->q};
   // eig_range[0] is unused (src/chebyshev.hpp:51); no per-call D2D copy of the diagonal (:53)
-  return cheb_iterate(
-      w, [A, s](double* in, double* out) { return laplacian_apply(A, in, out, s); }, laplacian_diag_inv(A),
-      l->size_local, sm->eig_max, sm->max_iter, x, b, need_r, x_zero, s, split);
+  const ApplyFn apply = [A, s](double* in, double* out) { return laplacian_apply(A, in, out, s); };
+  const ApplyFn apply_zeroed = [A, s](double* in, double* out) { return laplacian_apply_zeroed(A, in, out, s); };
+  return cheb_iterate(w, apply, laplacian_diag_inv(A), l->size_local, sm->eig_max, sm->max_iter, x, b, need_r, x_zero,
+                      s, split, laplacian_wants_zeroed_output(A) ? &apply_zeroed : nullptr, l->total());
 }
 
 // src/pmg.hpp:56-155 (lean form, see the file header)

@@ -77,6 +77,42 @@ void ew_launch(int n, bool vec_ok, F f, hipStream_t s)
     ew_kernel1<<<ew_blocks(n), EW_THREADS, 0, s>>>(0, n, f);
 }
 
+
+// F over the owned entries [0, n_owned), and q[0, n_total) = 0 behind it: the vector kernel that
+// consumes the operator's last output also clears it for the next application of an operator whose
+// launch accumulates with atomics (a small level's merged launch) -- no zero-fill kernel of its own.
+template <typename F>
+struct ThenClearF
+{
+  F f;
+  double* q;
+  int n_owned;
+  __device__ void pair(int i) const
+  {
+    if (2 * i + 1 < n_owned)
+    {
+      f.pair(i);
+      reinterpret_cast<double2*>(q)[i] = make_double2(0.0, 0.0);
+    }
+    else
+    {
+      one(2 * i);
+      one(2 * i + 1);
+    }
+  }
+  __device__ void one(int i) const
+  {
+    if (i < n_owned)
+      f.one(i);
+    q[i] = 0.0;
+  }
+};
+template <typename F>
+void ew_launch_clear(int n_owned, int n_total, bool vec_ok, F f, double* q, hipStream_t s)
+{
+  ew_launch(n_total, vec_ok && aligned16(q), ThenClearF<F>{f, q, n_owned}, s);
+}
+
 #define D2(p) reinterpret_cast<double2*>(p)
 #define CD2(p) reinterpret_cast<const double2*>(p)
 
@@ -505,20 +541,36 @@ void launch_pointwise(int n, double* w, const double* x, const double* y, hipStr
 {
   ew_launch(n, aligned16(w) && aligned16(x) && aligned16(y), MulF{w, x, y}, s);
 }
+// clear_q (optional): the operator's output vector, zeroed over [0, n_total) behind the update (ThenClearF)
 void launch_cheb_init(int n, double* r, double* z, const double* b, const double* q,
-                      const double* dinv, double c0, hipStream_t s)
+                      const double* dinv, double c0, hipStream_t s, double* clear_q, int n_total)
 {
   bool v = aligned16(r) && aligned16(z) && aligned16(b) && aligned16(dinv) && (!q || aligned16(q));
-  if (streams(n))
+  if (clear_q)
+  {
+    if (streams(n))
+      ew_launch_clear(n, n_total, v, ChebInitF<true>{r, z, b, q, dinv, c0}, clear_q, s);
+    else
+      ew_launch_clear(n, n_total, v, ChebInitF<false>{r, z, b, q, dinv, c0}, clear_q, s);
+  }
+  else if (streams(n))
     ew_launch(n, v, ChebInitF<true>{r, z, b, q, dinv, c0}, s);
   else
     ew_launch(n, v, ChebInitF<false>{r, z, b, q, dinv, c0}, s);
 }
 void launch_cheb_step(int n, double* x, double* r, double* z, const double* q, const double* dinv,
-                      double c1, double c2, bool both, bool x_final, hipStream_t s)
+                      double c1, double c2, bool both, bool x_final, hipStream_t s, double* clear_q, int n_total)
 {
-  const int xf = x_final ? 1 : 0;
   bool v = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(q) && aligned16(dinv);
+  const int xf = x_final ? 1 : 0;
+  if (clear_q) // small levels only (merged-launch operators): no streaming variants needed
+  {
+    if (both)
+      ew_launch_clear(n, n_total, v, ChebStepF<false, true>{x, r, z, q, dinv, c1, c2, xf}, clear_q, s);
+    else
+      ew_launch_clear(n, n_total, v, ChebStepF<false, false>{x, r, z, q, dinv, c1, c2, xf}, clear_q, s);
+    return;
+  }
   if (streams(n))
   {
     if (both)
@@ -539,11 +591,13 @@ void launch_cheb_residual(int n, double* r, const double* q, hipStream_t s)
     ew_launch(n, aligned16(r) && aligned16(q), ChebResidualF<false>{r, q}, s);
 }
 void launch_cheb_first(int n, double* x, double* r, double* z, const double* q, const double* dinv,
-                       double c1, double c2, bool x_final, hipStream_t s)
+                       double c1, double c2, bool x_final, hipStream_t s, double* clear_q, int n_total)
 {
   bool v = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(q) && aligned16(dinv);
   const int xf = x_final ? 1 : 0;
-  if (streams(n))
+  if (clear_q)
+    ew_launch_clear(n, n_total, v, ChebFirstF<false>{x, r, z, q, dinv, c1, c2, xf}, clear_q, s);
+  else if (streams(n))
     ew_launch(n, v, ChebFirstF<true>{x, r, z, q, dinv, c1, c2, xf}, s);
   else
     ew_launch(n, v, ChebFirstF<false>{x, r, z, q, dinv, c1, c2, xf}, s);

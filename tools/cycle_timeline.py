@@ -1,7 +1,7 @@
 """Where one V-cycle spends its time: the kernel trace of `pmg_main --cycles C` (rocprofv3 --kernel-trace csv)
 reduced to busy time per kernel family and idle time between kernels, for the cycles only.
 usage (GPU box):  cd /tmp && rocprofv3 --kernel-trace --output-format csv -d OUT -- <repo>/pmg-dolfinx_amd/bin/pmg_main --n 64 --cycles 10
-                  python tools/cycle_timeline.py OUT"""
+                  python tools/cycle_timeline.py OUT [cycles [fine-level stiffness launches per cycle]]"""
 import csv, glob, os, re, sys
 from collections import defaultdict
 
@@ -20,7 +20,7 @@ def family(n):
 # take the last fraction of the trace that holds `ncyc` repetitions of the per-cycle launch pattern
 ncyc = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 fine = [i for i, n in enumerate(names) if "stiffness_column_kernel<4" in n]
-per_cycle_fine = 7 * 8
+per_cycle_fine = int(sys.argv[3]) if len(sys.argv) > 3 else 7 * 8  # stiffness launches of the fine level per cycle
 start = fine[-ncyc * per_cycle_fine]
 # back up to the first kernel of that cycle (kernels between the previous cycle's last fine launch and this one)
 prev = fine[-ncyc * per_cycle_fine - 1]
