@@ -86,6 +86,11 @@ def main():
                     help="N > 1: halo + reductions on the library's own RCCL communicator (default) or through "
                          "torch.distributed callbacks")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaled config-3 measurement")
+    ap.add_argument("--graph-exchange", action="store_true",
+                    help="N > 1 with the library's communicator: additionally time the cycles replayed as a hipGraph "
+                         "with the halo exchange captured on the compute stream (one hipGraphLaunch instead of ~115 us "
+                         "of host time per exchange; validated on one GPU with a rank as its own partner, "
+                         "tests/test_gpu_distributed.py, not yet between GPUs -- hence opt-in)")
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="N = 1: run the multi-rank code path (process group, communicator bootstrap, strong-scaling "
                          "block) with a group of one rank -- a rehearsal on a single-GPU box, not a measurement")
@@ -173,7 +178,7 @@ def main():
     counts = H.mg.apply_counts()
     # the same K cycles replayed as a hipGraph (one launch per cycle instead of ~120; single rank only)
     graph_ms = None
-    if not multi:
+    if not multi or (args.graph_exchange and comm is not None):
         H.mg.set_graph(True)
         for _ in range(2):
             H.mg.apply(b, x)
@@ -264,8 +269,9 @@ def main():
     }
     if graph_ms is not None:
         out["graph_replay"] = {"ms_per_step": graph_ms, "value": fine_dofs_global / (graph_ms * 1e-3), "unit": "DoF/s",
-                               "note": "the same cycle replayed with one hipGraphLaunch per cycle; `value` above is "
-                                       "the eager (stream-ordered launches) figure"}
+                               "note": "the same cycle replayed with one hipGraphLaunch per cycle"
+                                       + (" (halo exchange captured on the compute stream)" if multi else "")
+                                       + "; `value` above is the eager (stream-ordered launches) figure"}
 
     def timed_cycles(Hx, bx, xx, k):
         sync_all()
@@ -296,6 +302,14 @@ def main():
                                  "ms_per_step": 1e3 * ts / args.steps, "fine_dofs_global": nd_s,
                                  "local_dofs": [lv.size_local for lv in Hs.levels],
                                  "ghosts": [lv.num_ghosts for lv in Hs.levels]}
+        if args.graph_exchange and comm is not None:  # the host-bound case the captured exchange is for
+            Hs.mg.set_graph(True)
+            for _ in range(2):
+                Hs.mg.apply(Hs.rhs[-1], xs_)
+            tg_s = timed_cycles(Hs, Hs.rhs[-1], xs_, args.steps)
+            Hs.mg.set_graph(False)
+            out["strong_scaling"]["graph_replay"] = {"ms_per_step": 1e3 * tg_s / args.steps,
+                                                     "value": nd_s * args.steps / tg_s, "unit": "DoF/s"}
         del Hs, xs_
 
     # ---- the cycle with its coarsest level SOLVED (the reference's --amg, examples/pmg/main.cpp:331-335): the

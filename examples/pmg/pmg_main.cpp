@@ -18,6 +18,8 @@
 //                    communicator.  Rank and world size come from --rank / RANK (OMPI_COMM_WORLD_RANK,
 //                    PMI_RANK); the GPU from LOCAL_RANK; rank 0 publishes the communicator id in
 //                    --id-file.  examples/pmg/run_ranks.sh launches the processes.
+//   --graph          time the cycles as hipGraph replays (one launch per cycle; with --ranks the grouped send/recv of
+//                    every halo exchange are captured on the compute stream: no host work per exchange)
 //   --check-partition px,py,pz   host-only consistency check of the brick partition (no GPU)
 //   --output FILE    write the solution as a legacy VTK file of the fine-level GLL points (:369-379)
 #define PMG_AMD_DOLFINX_NAMESPACE
@@ -69,7 +71,7 @@ struct Options : examples::RankOptions
 {
   int n = 64, cheb_its = 3, cycles = 10, amg_cycles = 0;
   std::vector<int> orders = {1, 2, 4};
-  bool pcg = false, coarse_cg = false, use_amg = false, random_rhs = false;
+  bool pcg = false, coarse_cg = false, use_amg = false, random_rhs = false, graph = false;
   std::string output;
 };
 using examples::parse3;
@@ -244,6 +246,9 @@ void solve(const Options& o)
       std::printf("Norm of x = %.15e\n", xn);
   }
 
+  // --graph: the timed cycles replayed as one hipGraph each (with --ranks: the halo exchange captured with them)
+  if (o.graph)
+    check(pmg_multigrid_set_graph(pmg.handle(), 1));
   // timing of the cycle alone (no residual evaluation)
   hipEvent_t e0, e1;
   hip_check(hipEventCreate(&e0), "event");
@@ -258,8 +263,12 @@ void solve(const Options& o)
   float ms = 0;
   hip_check(hipEventElapsedTime(&ms, e0, e1), "elapsed");
   if (root)
-    std::printf("V-cycle: %.3f ms, %.3f GDoF/s\n", ms / reps,
-                (double)mesh.global_ndofs(order.back()) / (ms * 1e-3 / reps) * 1e-9);
+    std::printf("V-cycle: %.3f ms, %.3f GDoF/s%s\n", ms / reps,
+                (double)mesh.global_ndofs(order.back()) / (ms * 1e-3 / reps) * 1e-9,
+                o.graph ? (pmg_multigrid_graph_replays(pmg.handle()) > 0 ? " (hipGraph replays)" : " (not capturable: eager)")
+                        : "");
+  if (o.graph)
+    check(pmg_multigrid_set_graph(pmg.handle(), 0));
 
   if (o.pcg)
   {
@@ -345,6 +354,8 @@ int main(int argc, char** argv)
         o.pcg = true;
       else if (!std::strcmp(argv[i], "--random-rhs"))
         o.random_rhs = true;
+      else if (!std::strcmp(argv[i], "--graph"))
+        o.graph = true;
       else if (!std::strcmp(argv[i], "--coarse-cg"))
         o.coarse_cg = true;
       else if (!std::strcmp(argv[i], "--amg"))
@@ -369,7 +380,7 @@ int main(int argc, char** argv)
       else
       {
         std::cout << "usage: pmg [--n cells_per_direction | --ndofs N_per_rank] [--orders 1,2,4] [--smoother-its K]\n"
-                     "           [--cycles C] [--pcg [--random-rhs]] [--amg | --amg-cycles N | --coarse-cg]\n"
+                     "           [--cycles C] [--pcg [--random-rhs]] [--amg | --amg-cycles N | --coarse-cg] [--graph]\n"
                      "           [--ranks px,py,pz [--rank r] [--id-file F]] [--native-comm] [--output FILE]\n"
                      "           [--check-partition px,py,pz]\n";
         return !std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h") ? 0 : 2;

@@ -389,9 +389,11 @@ int pmg_multigrid_apply(pmg_multigrid mg, const double* rhs, double* y, double* 
 /* hipGraph replay of the cycle.  With enable != 0, pmg_multigrid_apply (and the V-cycle preconditioner
  * inside pmg_cg_solve) captures the cycle's ~120 launches into a graph the first time it sees a
  * (rhs, y) pair and replays it afterwards with one hipGraphLaunch on the caller's stream: same
- * kernels, same order, same results.  Captured only when nothing in the cycle needs the host: a
- * single rank, no Krylov / callback coarse solver, no in-situ profiling; otherwise the call runs
- * eagerly as before.  A change of a smoother's iteration count or bound, of a geometry mode or of the
+ * kernels, same order, same results.  Captured only when nothing in the cycle needs the host: no
+ * exchange callbacks, no Krylov / callback coarse solver, no in-situ profiling; otherwise the call runs
+ * eagerly as before.  Layouts with a pmg_comm ARE captured: the grouped send / receive of every halo
+ * exchange is recorded on the capture stream, so a replayed cycle costs the host one launch instead of
+ * ~115 us per exchange (and gives up the overlap of the exchange with the interior cells).  A change of a smoother's iteration count or bound, of a geometry mode or of the
  * coarse solver is noticed (new graph); calling this function again drops the cached graphs (do that
  * after replacing an operator's diagonal or any caller-owned array in place). */
 int pmg_multigrid_set_graph(pmg_multigrid mg, int enable);

@@ -187,8 +187,20 @@ int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s)
   pmg_comm c = l->comm;
   if (l->nb_rank.empty()) // no partner: nothing to post (point-to-point groups are not collectives)
     return PMG_OK;
-  PMG_HIP(hipEventRecord(l->ev_packed, s));
-  PMG_HIP(hipStreamWaitEvent(c->stream, l->ev_packed, 0));
+  // While `s` is being captured into a graph the group is issued on `s` itself (RCCL captures its kernels into
+  // the graph; forking to the communicator's stream inside a capture crashes RCCL 2.26): the replayed cycle costs
+  // the host one hipGraphLaunch instead of ~115 us per exchange, at the price of the overlap with the interior
+  // cells -- the trade for a strong-scaled level, where the host is the bound.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  PMG_HIP(hipStreamIsCapturing(s, &cap));
+  const bool inline_group = cap == hipStreamCaptureStatusActive;
+  hipStream_t cs = inline_group ? s : c->stream;
+  l->exchange_inline = inline_group;
+  if (!inline_group)
+  {
+    PMG_HIP(hipEventRecord(l->ev_packed, s));
+    PMG_HIP(hipStreamWaitEvent(c->stream, l->ev_packed, 0));
+  }
   const double* out = reverse ? l->recv_buf : l->send_buf;
   double* in = reverse ? l->send_buf : l->recv_buf;
   const std::vector<int32_t>& nout = reverse ? l->nb_recv : l->nb_send;
@@ -199,22 +211,23 @@ int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s)
   for (size_t i = 0; i < l->nb_rank.size() && r == ncclSuccess; ++i)
   {
     if (nout[i] > 0)
-      r = g_rccl.Send(out + so, (size_t)nout[i], ncclDouble, l->nb_rank[i], c->comm, c->stream);
+      r = g_rccl.Send(out + so, (size_t)nout[i], ncclDouble, l->nb_rank[i], c->comm, cs);
     if (nin[i] > 0 && r == ncclSuccess)
-      r = g_rccl.Recv(in + ro, (size_t)nin[i], ncclDouble, l->nb_rank[i], c->comm, c->stream);
+      r = g_rccl.Recv(in + ro, (size_t)nin[i], ncclDouble, l->nb_rank[i], c->comm, cs);
     so += nout[i];
     ro += nin[i];
   }
   ncclResult_t re = g_rccl.GroupEnd(); // always close the group
   PMG_NCCL(r);
   PMG_NCCL(re);
-  PMG_HIP(hipEventRecord(l->ev_arrived, c->stream));
+  if (!inline_group)
+    PMG_HIP(hipEventRecord(l->ev_arrived, c->stream));
   return PMG_OK;
 }
 
 int comm_exchange_end(pmg_layout l, hipStream_t s)
 {
-  if (l->nb_rank.empty())
+  if (l->nb_rank.empty() || l->exchange_inline)
     return PMG_OK;
   PMG_HIP(hipStreamWaitEvent(s, l->ev_arrived, 0));
   return PMG_OK;

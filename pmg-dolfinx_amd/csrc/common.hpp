@@ -90,6 +90,7 @@ struct pmg_layout_s
   pmg_comm_s* comm = nullptr;
   std::vector<int32_t> nb_rank, nb_send, nb_recv; // neighbour ranks and per-neighbour counts
   hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
+  bool exchange_inline = false; // the exchange in flight was issued on the compute stream (graph capture)
   const int32_t* send_idx = nullptr;
   const int32_t* recv_idx = nullptr;
   double* send_buf = nullptr;

@@ -656,10 +656,10 @@ long long capture_config(pmg_multigrid mg)
   for (int i = 0; i < mg->L; ++i)
   {
     pmg_layout l = mg->layouts[i];
-    // halo: the caller's callbacks are host code inside the cycle; capturing the library's grouped
-    // ncclSend / ncclRecv (communicator stream forked and joined with events) crashes inside RCCL 2.26
-    // (tried on one rank that is its own partner), so a layout with a communicator runs eagerly too
-    if (l->comm || l->exchange)
+    // halo: the caller's callbacks are host code inside the cycle.  The library's grouped ncclSend / ncclRecv are
+    // captured on the capture stream itself (comm_exchange_begin; forking to the communicator's stream inside a
+    // capture crashes RCCL 2.26).
+    if (l->exchange && !l->comm)
       return -1;
     const long long st = laplacian_capture_state(mg->ops[i]);
     if (st < 0)

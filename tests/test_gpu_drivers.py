@@ -201,3 +201,13 @@ def test_vector_update_driver(built, tmp_path):
         assert "Ghost check" in out
         (nx,) = grab(r"Norm of x = (\S+)", out)
         assert abs(nx - 100 * np.sqrt(nd)) < 1e-10 * nx
+
+
+def test_pmg_driver_graph_replay(built, tmp_path):
+    """--graph: the timed cycles run as hipGraph replays, also on a layout with the RCCL communicator."""
+    for extra in ([], ["--native-comm", "--id-file", str(tmp_path / "id")]):
+        out = run("pmg_main", "--n", 6, "--orders", "1,2,4", "--cycles", 2, "--graph", *extra)
+        assert "(hipGraph replays)" in out
+        ref = run("pmg_main", "--n", 6, "--orders", "1,2,4", "--cycles", 2, *extra)
+        (a,), (b,) = grab(r"Cycle 2: residual norm = (\S+)", out), grab(r"Cycle 2: residual norm = (\S+)", ref)
+        assert abs(a - b) < 1e-10 * b  # atomic-order noise of the merged launches
