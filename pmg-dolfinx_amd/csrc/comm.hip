@@ -237,6 +237,13 @@ int comm_exchange_end(pmg_layout l, hipStream_t s)
 int comm_allreduce(pmg_layout l, double* d_values, int n, bool max, hipStream_t s)
 {
   pmg_comm c = l->comm;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  PMG_HIP(hipStreamIsCapturing(s, &cap));
+  if (cap == hipStreamCaptureStatusActive) // inside a graph capture: on `s` itself (see comm_exchange_begin)
+  {
+    PMG_NCCL(g_rccl.AllReduce(d_values, d_values, (size_t)n, ncclDouble, max ? ncclMax : ncclSum, c->comm, s));
+    return PMG_OK;
+  }
   PMG_HIP(hipEventRecord(c->ev_in, s));
   PMG_HIP(hipStreamWaitEvent(c->stream, c->ev_in, 0));
   PMG_NCCL(g_rccl.AllReduce(d_values, d_values, (size_t)n, ncclDouble, max ? ncclMax : ncclSum, c->comm,

@@ -537,7 +537,19 @@ def _self_partner_graph_body(rank, world, port):
         xg, r1 = cycles(H, True)
         out["replays"] = r1 - r0
         out["graph_vs_eager"] = float(np.abs(xg - xe).max() / np.abs(xe).max())
-        del H
+        # ... and with the replicated AMG coarse solve, whose all-reduce is captured the same way
+        lv0 = H.levels[0]
+        # (one rank, so the "global" numbering is the owned one; the ghost dofs, owned by nobody here, are folded
+        # onto owned ones -- a glued mesh, still a symmetric positive definite coarse matrix)
+        gi = np.concatenate([np.arange(lv0.size_local), np.arange(lv0.num_ghosts) % lv0.size_local]).astype(np.int64)
+        amg = pm.AmgSolver(H.operators[0], global_index=gi, n_global=lv0.size_local, cycles=2)
+        H.mg.set_coarse_solver(amg)
+        xa, r2 = cycles(H, False)
+        xb, r3 = cycles(H, True)
+        out["amg_replays"] = r3 - r2
+        out["amg_graph_vs_eager"] = float(np.abs(xb - xa).max() / np.abs(xa).max())
+        H.mg.set_coarse_solver(None)
+        del amg, H
         problem.make_layout = lambda lv, group=None, device="cuda", comm=None: pm.Layout(
             lv.size_local, lv.num_ghosts, device=device)
         H = pm.PoissonHierarchy((4, 4, 8), (1, 2, 4), cheb_its=3, proc_dims=(1, 1, 2), rank=0, size=2)
@@ -562,3 +574,4 @@ def test_graph_replay_captures_the_rccl_exchange(built):
     assert out["replays"] >= 3  # captured on the first cycle, replayed afterwards
     assert out["graph_vs_eager"] < 1e-12  # tolerance: atomic-order noise of the merged launches
     assert out["exchange_matters"] > 1e-6  # the check is sensitive to what the exchange moves
+    assert out["amg_replays"] >= 3 and out["amg_graph_vs_eager"] < 1e-12
