@@ -512,11 +512,16 @@ def _self_partner_graph_body(rank, world, port):
     native = pm.RcclComm(0, 1, pm.RcclComm.unique_id())
     orig = problem.make_layout
 
-    def self_layout(comm):
+    def self_layout(comm, reverse=False):
+        # reverse: the same (owned dof -> ghost) pairs listed backwards -- the same exchange through different
+        # pack / unpack lists
         def make(lv, group=None, device="cuda", comm_=None, **kw):
             m = min(sum(lv.send_counts), sum(lv.recv_counts))
+            si, ri = np.asarray(lv.send_indices[:m]), np.asarray(lv.recv_indices[:m])
+            if reverse:
+                si, ri = si[::-1].copy(), ri[::-1].copy()
             return pm.Layout(lv.size_local, lv.num_ghosts, [0] if m else [], [m] if m else [], [m] if m else [],
-                             lv.send_indices[:m], lv.recv_indices[:m], device=device, comm=comm)
+                             si, ri, device=device, comm=comm)
         return lambda lv, group=None, device="cuda", comm=None: make(lv, group, device)
 
     def cycles(H, graph):
@@ -550,6 +555,12 @@ def _self_partner_graph_body(rank, world, port):
         out["amg_graph_vs_eager"] = float(np.abs(xb - xa).max() / np.abs(xa).max())
         H.mg.set_coarse_solver(None)
         del amg, H
+        # the same halo with its index lists in another order
+        problem.make_layout = self_layout(native, reverse=True)
+        H = pm.PoissonHierarchy((4, 4, 8), (1, 2, 4), cheb_its=3, proc_dims=(1, 1, 2), rank=0, size=2)
+        xs, _ = cycles(H, False)
+        out["reordered_lists"] = float(np.abs(xs - xe).max() / np.abs(xe).max())
+        del H
         problem.make_layout = lambda lv, group=None, device="cuda", comm=None: pm.Layout(
             lv.size_local, lv.num_ghosts, device=device)
         H = pm.PoissonHierarchy((4, 4, 8), (1, 2, 4), cheb_its=3, proc_dims=(1, 1, 2), rank=0, size=2)
@@ -575,3 +586,4 @@ def test_graph_replay_captures_the_rccl_exchange(built):
     assert out["graph_vs_eager"] < 1e-12  # tolerance: atomic-order noise of the merged launches
     assert out["exchange_matters"] > 1e-6  # the check is sensitive to what the exchange moves
     assert out["amg_replays"] >= 3 and out["amg_graph_vs_eager"] < 1e-12
+    assert out["reordered_lists"] < 1e-12
