@@ -174,6 +174,33 @@ extern "C" int pmg_layout_set_comm(pmg_layout l, pmg_comm comm, int32_t n_neighb
     PMG_HIP(hipEventCreateWithFlags(&l->ev_packed, hipEventDisableTiming));
   if (!l->ev_arrived)
     PMG_HIP(hipEventCreateWithFlags(&l->ev_arrived, hipEventDisableTiming));
+  // padded staging buffers: one 256-byte aligned segment per neighbour
+  constexpr size_t ALIGN = 32; // doubles
+  auto layout_side = [&](const std::vector<int32_t>& counts, std::vector<size_t>& off, double** buf,
+                         int32_t** pos) -> int {
+    off.assign(counts.size(), 0);
+    std::vector<int32_t> h;
+    size_t at = 0;
+    for (size_t k = 0; k < counts.size(); ++k)
+    {
+      off[k] = at;
+      for (int32_t j = 0; j < counts[k]; ++j)
+        h.push_back((int32_t)(at + (size_t)j));
+      at = (at + (size_t)counts[k] + ALIGN - 1) / ALIGN * ALIGN;
+    }
+    (void)hipFree(*buf);
+    (void)hipFree(*pos);
+    *buf = nullptr;
+    *pos = nullptr;
+    PMG_HIP(hipMalloc(buf, sizeof(double) * (at ? at : 1)));
+    PMG_HIP(hipMemset(*buf, 0, sizeof(double) * (at ? at : 1)));
+    PMG_HIP(hipMalloc(pos, sizeof(int32_t) * (h.empty() ? 1 : h.size())));
+    if (!h.empty())
+      PMG_HIP(hipMemcpy(*pos, h.data(), sizeof(int32_t) * h.size(), hipMemcpyHostToDevice));
+    return PMG_OK;
+  };
+  PMG_TRY(layout_side(l->nb_send, l->send_off, &l->c_send, &l->send_pos));
+  PMG_TRY(layout_side(l->nb_recv, l->recv_off, &l->c_recv, &l->recv_pos));
   return PMG_OK;
 }
 
@@ -201,21 +228,20 @@ int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s)
     PMG_HIP(hipEventRecord(l->ev_packed, s));
     PMG_HIP(hipStreamWaitEvent(c->stream, l->ev_packed, 0));
   }
-  const double* out = reverse ? l->recv_buf : l->send_buf;
-  double* in = reverse ? l->send_buf : l->recv_buf;
+  const double* out = reverse ? l->c_recv : l->c_send;
+  double* in = reverse ? l->c_send : l->c_recv;
   const std::vector<int32_t>& nout = reverse ? l->nb_recv : l->nb_send;
   const std::vector<int32_t>& nin = reverse ? l->nb_send : l->nb_recv;
+  const std::vector<size_t>& oout = reverse ? l->recv_off : l->send_off;
+  const std::vector<size_t>& oin = reverse ? l->send_off : l->recv_off;
   PMG_NCCL(g_rccl.GroupStart());
-  size_t so = 0, ro = 0;
   ncclResult_t r = ncclSuccess;
   for (size_t i = 0; i < l->nb_rank.size() && r == ncclSuccess; ++i)
   {
     if (nout[i] > 0)
-      r = g_rccl.Send(out + so, (size_t)nout[i], ncclDouble, l->nb_rank[i], c->comm, cs);
+      r = g_rccl.Send(out + oout[i], (size_t)nout[i], ncclDouble, l->nb_rank[i], c->comm, cs);
     if (nin[i] > 0 && r == ncclSuccess)
-      r = g_rccl.Recv(in + ro, (size_t)nin[i], ncclDouble, l->nb_rank[i], c->comm, cs);
-    so += nout[i];
-    ro += nin[i];
+      r = g_rccl.Recv(in + oin[i], (size_t)nin[i], ncclDouble, l->nb_rank[i], c->comm, cs);
   }
   ncclResult_t re = g_rccl.GroupEnd(); // always close the group
   PMG_NCCL(r);

@@ -46,6 +46,26 @@ __global__ void unpack_add_kernel(int n, const int32_t* __restrict__ idx,
     atomicAdd(&out[idx[i]], in[i]);
 }
 
+// the same through a position list of the staging buffer (padded per-neighbour segments, comm.hip)
+__global__ void pack_pos_kernel(int n, const int32_t* __restrict__ idx, const int32_t* __restrict__ pos,
+                                const double* __restrict__ in, double* __restrict__ out)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[pos[i]] = in[idx[i]];
+}
+__global__ void unpack_pos_kernel(int n, const int32_t* __restrict__ idx, const int32_t* __restrict__ pos,
+                                  const double* __restrict__ in, double* __restrict__ out)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[idx[i]] = in[pos[i]];
+}
+__global__ void unpack_add_pos_kernel(int n, const int32_t* __restrict__ idx, const int32_t* __restrict__ pos,
+                                      const double* __restrict__ in, double* __restrict__ out)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    atomicAdd(&out[idx[i]], in[pos[i]]);
+}
+
 // ---- generic element-wise launcher: F::apply(i, args...) on doubles ----
 // pairs [0, n2) plus, when `tail` >= 0, the single trailing element (odd lengths)
 template <typename F>
@@ -754,6 +774,10 @@ extern "C" int pmg_layout_destroy(pmg_layout l)
     (void)hipEventDestroy(l->ev_packed);
   if (l->ev_arrived)
     (void)hipEventDestroy(l->ev_arrived);
+  (void)hipFree(l->c_send);
+  (void)hipFree(l->c_recv);
+  (void)hipFree(l->send_pos);
+  (void)hipFree(l->recv_pos);
   delete l;
   return PMG_OK;
 }
@@ -778,8 +802,13 @@ extern "C" int pmg_scatter_fwd_begin(pmg_layout l, const double* x, pmg_stream s
     return PMG_OK; // single rank
   }
   if (l->n_send > 0)
-    pack_kernel<<<ew_blocks(l->n_send), EW_THREADS, 0, S(stream)>>>(l->n_send, l->send_idx, x,
-                                                                    l->send_buf);
+  {
+    if (l->comm)
+      pack_pos_kernel<<<ew_blocks(l->n_send), EW_THREADS, 0, S(stream)>>>(l->n_send, l->send_idx, l->send_pos, x,
+                                                                          l->c_send);
+    else
+      pack_kernel<<<ew_blocks(l->n_send), EW_THREADS, 0, S(stream)>>>(l->n_send, l->send_idx, x, l->send_buf);
+  }
   PMG_HIP(hipGetLastError());
   if (l->comm)
     return comm_exchange_begin(l, false, S(stream));
@@ -799,8 +828,14 @@ extern "C" int pmg_scatter_fwd_end(pmg_layout l, double* x, pmg_stream stream)
   else if (l->exchange(l->user, 1, stream) != 0)
     return fail(PMG_ERR_INVALID, "exchange callback (end) failed");
   if (l->n_recv > 0)
-    unpack_kernel<<<ew_blocks(l->n_recv), EW_THREADS, 0, S(stream)>>>(
-        l->n_recv, l->recv_idx, l->recv_buf, x + l->size_local);
+  {
+    if (l->comm)
+      unpack_pos_kernel<<<ew_blocks(l->n_recv), EW_THREADS, 0, S(stream)>>>(l->n_recv, l->recv_idx, l->recv_pos,
+                                                                            l->c_recv, x + l->size_local);
+    else
+      unpack_kernel<<<ew_blocks(l->n_recv), EW_THREADS, 0, S(stream)>>>(l->n_recv, l->recv_idx, l->recv_buf,
+                                                                        x + l->size_local);
+  }
   PMG_HIP(hipGetLastError());
   return PMG_OK;
 }
@@ -817,8 +852,14 @@ extern "C" int pmg_scatter_rev_begin(pmg_layout l, const double* x, pmg_stream s
     return PMG_OK; // single rank
   }
   if (l->n_recv > 0)
-    pack_kernel<<<ew_blocks(l->n_recv), EW_THREADS, 0, S(stream)>>>(
-        l->n_recv, l->recv_idx, x + l->size_local, l->recv_buf);
+  {
+    if (l->comm)
+      pack_pos_kernel<<<ew_blocks(l->n_recv), EW_THREADS, 0, S(stream)>>>(l->n_recv, l->recv_idx, l->recv_pos,
+                                                                          x + l->size_local, l->c_recv);
+    else
+      pack_kernel<<<ew_blocks(l->n_recv), EW_THREADS, 0, S(stream)>>>(l->n_recv, l->recv_idx, x + l->size_local,
+                                                                      l->recv_buf);
+  }
   PMG_HIP(hipGetLastError());
   if (l->comm)
     return comm_exchange_begin(l, true, S(stream));
@@ -838,8 +879,13 @@ extern "C" int pmg_scatter_rev_end(pmg_layout l, double* x, pmg_stream stream)
   else if (l->exchange(l->user, 3, stream) != 0)
     return fail(PMG_ERR_INVALID, "exchange callback (rev end) failed");
   if (l->n_send > 0)
-    unpack_add_kernel<<<ew_blocks(l->n_send), EW_THREADS, 0, S(stream)>>>(l->n_send, l->send_idx,
-                                                                          l->send_buf, x);
+  {
+    if (l->comm)
+      unpack_add_pos_kernel<<<ew_blocks(l->n_send), EW_THREADS, 0, S(stream)>>>(l->n_send, l->send_idx, l->send_pos,
+                                                                                l->c_send, x);
+    else
+      unpack_add_kernel<<<ew_blocks(l->n_send), EW_THREADS, 0, S(stream)>>>(l->n_send, l->send_idx, l->send_buf, x);
+  }
   PMG_HIP(hipGetLastError());
   return PMG_OK;
 }

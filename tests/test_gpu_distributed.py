@@ -587,3 +587,51 @@ def test_graph_replay_captures_the_rccl_exchange(built):
     assert out["exchange_matters"] > 1e-6  # the check is sensitive to what the exchange moves
     assert out["amg_replays"] >= 3 and out["amg_graph_vs_eager"] < 1e-12
     assert out["reordered_lists"] < 1e-12
+
+
+def _segments_body(rank, world, port):
+    """Several neighbour segments (here: three, all to the rank itself) through the library's communicator: the
+    per-neighbour offsets of the padded staging buffers, forward and reverse."""
+    import torch
+
+    import pmg_dolfinx_amd as pm
+
+    torch.cuda.set_device(0)
+    comm = pm.RcclComm(0, 1, pm.RcclComm.unique_id())
+    n_local, counts = 5000, [37, 1001, 64]  # odd lengths: every later segment would start unaligned without padding
+    m = sum(counts)
+    rng = np.random.default_rng(3)
+    send = rng.permutation(n_local)[:m].astype(np.int32)  # distinct owned dofs
+    recv = rng.permutation(m).astype(np.int32)            # ghosts in a scrambled order
+    lay = pm.Layout(n_local, m + 5, [0, 0, 0], counts, counts, send, recv, comm=comm)
+    x = pm.Vector(lay)
+    x0 = rng.standard_normal(n_local + m + 5)
+    x.data.copy_(torch.as_tensor(x0, device="cuda"))
+    x.scatter_fwd()
+    torch.cuda.synchronize()
+    xf = x.data_copy()
+    ref = x0.copy()
+    ref[n_local + recv] = x0[send]
+    out = {"fwd": float(np.abs(xf - ref).max())}
+    x.scatter_rev_begin()
+    x.scatter_rev_end()
+    torch.cuda.synchronize()
+    xr = x.data_copy()
+    ref2 = ref.copy()
+    np.add.at(ref2, send, ref[n_local + recv])
+    out["rev"] = float(np.abs(xr - ref2).max())
+    return out
+
+
+def _segments_worker(rank, world, port, q):
+    _reporting(_segments_body)(rank, world, port, q)
+
+
+def test_native_exchange_with_several_segments(built):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    (out,) = _run_ranks(_segments_worker, 1, ())
+    assert out["fwd"] == 0.0
+    assert out["rev"] < 1e-14
