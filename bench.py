@@ -61,13 +61,7 @@ class extra:
         return False
 
 
-def main():
-    # The contract is ONE JSON line on stdout.  Libraries underneath write to the process's stdout on their own
-    # (RCCL prints a version banner when a communicator is created), so file descriptor 1 is pointed at stderr
-    # for the whole run and the line goes out through a private duplicate of the original stdout.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -96,7 +90,71 @@ def main():
                          "block) with a group of one rank -- a rehearsal on a single-GPU box, not a measurement")
     ap.add_argument("--mesh-sweep", action="store_true",
                     help="N = 1: PCG iteration counts at 32^3 / 64^3 / 96^3 with a random right-hand side")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+class LaunchError(SystemExit):
+    """The run cannot measure what was asked for (rank count, devices): message on stderr, exit code 2,
+    nothing on stdout -- never a line for a different number of GPUs than `--gpus`."""
+
+    def __init__(self, msg):
+        log("bench.py: " + msg)
+        super().__init__(2)
+
+
+def free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def visible_gpus() -> int:
+    """Devices this process could use.  `torch.cuda.device_count()` does not initialise the GPU on this image,
+    so a parent that only counts may still start child ranks."""
+    import torch
+
+    try:
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher (the reference: `srun -n 8`, examples/pmg/submit.sh:29):
+    start the N ranks as CHILD processes of a process that has not touched the GPU
+    (`python -m torch.distributed.run`, one rank per GPU), hand their stdout (rank 0's JSON line) through
+    and return the launcher's exit code."""
+    import subprocess
+
+    have = visible_gpus()
+    if have < args.gpus:
+        raise LaunchError(f"--gpus {args.gpus} asked for, {have} GPU(s) visible: refusing to run "
+                          f"(a {have or 1}-rank measurement must not be labelled {args.gpus} GPUs)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: no launcher in the environment, starting the ranks: " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise LaunchError(f"--gpus {args.gpus}: need at least one")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(self_launch(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise LaunchError(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    # The contract is ONE JSON line on stdout.  Libraries underneath write to the process's stdout on their own
+    # (RCCL prints a version banner when a communicator is created), so file descriptor 1 is pointed at stderr
+    # for the whole run and the line goes out through a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -106,8 +164,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    assert world == args.gpus
+    if visible_gpus() <= local_rank:
+        raise LaunchError(f"rank {rank}: local rank {local_rank} has no GPU ({visible_gpus()} visible); bench.py needs "
+                          f"one GPU per rank (there is no CPU fallback of the product path)")
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU (there is no CPU fallback of the product path)")
     torch.cuda.set_device(local_rank)
@@ -116,7 +176,8 @@ def main():
     multi = world > 1 or args.rehearse_comm
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:  # only the one-rank rehearsal gets here without a launcher
+            os.environ["MASTER_PORT"] = str(free_port())
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if rank == 0:
         ge.build()
@@ -140,6 +201,10 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             comm = None  # all ranks on the same route
+
+    rccl_ranks = (comm.size() if comm is not None else dist.get_world_size()) if multi else 1
+    if rccl_ranks != args.gpus:
+        raise LaunchError(f"[rank {rank}] the communicator has {rccl_ranks} rank(s), --gpus is {args.gpus}")
 
     t0 = time.time()
     H = pm.PoissonHierarchy(n_global, orders, kappa=2.0, cheb_its=args.cheb, proc_dims=dims, rank=rank, size=world,
@@ -264,6 +329,9 @@ def main():
             "exchange": ("library RCCL communicator (grouped send/recv, device all-reduce)" if comm is not None
                          else (comm_note or "torch.distributed callbacks")) if multi else "none (single rank)",
             "stiffness_launches_per_cycle": {f"p{p}": c for p, c in zip(orders, counts)},
+            # ranks of the communicator the halo and the reductions really ran on (pmg_comm_size of the library's
+            # RCCL communicator, or torch.distributed's RCCL group on the callback route); 1 = no communicator
+            "rccl_ranks": rccl_ranks,
         },
         "roofline": roofline,
     }

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <filesystem>
 #include <fstream>
 #include <initializer_list>
 #include <memory>
@@ -64,8 +65,13 @@ inline std::shared_ptr<const pmg_amd::Communicator> bootstrap(const RankOptions&
   if (size == 1 && !o.native_comm)
     return nullptr;
   std::array<char, PMG_COMM_ID_BYTES> id{};
+  // A file left by an earlier run must not hand a stale id to this one: rank 0 removes it before it creates the
+  // new id, and the other ranks accept only a file written after they started (minus a margin for launchers
+  // that start rank 0 first).
+  const auto started = std::filesystem::file_time_type::clock::now() - std::chrono::seconds(30);
   if (o.rank == 0)
   {
+    std::remove(o.id_file.c_str());
     id = pmg_amd::Communicator::unique_id();
     const std::string tmp = o.id_file + ".tmp";
     {
@@ -78,14 +84,22 @@ inline std::shared_ptr<const pmg_amd::Communicator> bootstrap(const RankOptions&
   {
     for (int tries = 0;; ++tries)
     {
-      std::ifstream f(o.id_file, std::ios::binary);
-      if (f && f.read(id.data(), id.size()))
-        break;
+      std::error_code ec;
+      const auto written = std::filesystem::last_write_time(o.id_file, ec);
+      if (!ec && written >= started)
+      {
+        std::ifstream f(o.id_file, std::ios::binary);
+        if (f && f.read(id.data(), id.size()))
+          break;
+      }
       if (tries > 600)
         throw std::runtime_error("timed out waiting for the communicator id in " + o.id_file);
       std::this_thread::sleep_for(std::chrono::milliseconds(100));
     }
   }
-  return std::make_shared<const pmg_amd::Communicator>(o.rank, size, id);
+  auto comm = std::make_shared<const pmg_amd::Communicator>(o.rank, size, id); // collective: every rank has read the id
+  if (o.rank == 0)
+    std::remove(o.id_file.c_str()); // a finished bootstrap leaves no file behind
+  return comm;
 }
 } // namespace examples

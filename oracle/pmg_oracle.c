@@ -36,6 +36,12 @@ typedef struct
   const int8_t* bc;
   double D[ORC_MAXND * ORC_MAXND];
   double* dinv; /* owned */
+  /* cell colouring for the scatter-add (owned): cells of one colour share no dof, so the threads of
+   * a colour add without atomics.  This is how a CPU implementation gets a deterministic, contention-free
+   * scatter; the reference's GPU kernel uses atomicAdd (src/laplacian.hpp:277), its CPU path assembles. */
+  int ncolors;
+  int* color_off;   /* [ncolors+1] */
+  int* color_cells; /* [ncells], grouped by colour, ascending inside a colour */
 } orc_level;
 
 typedef struct
@@ -118,6 +124,53 @@ orc_level* orc_level_create(int P, int ncells, int ndofs, const int32_t* dofmap,
   l->dinv = (double*)malloc(sizeof(double) * ndofs);
   for (int i = 0; i < ndofs; ++i)
     l->dinv[i] = 1.0;
+  /* greedy colouring: a cell takes the lowest colour none of its dofs has seen yet (64 colours at most;
+   * a structured hex mesh needs 8) */
+  {
+    uint64_t* used = (uint64_t*)calloc(ndofs > 0 ? ndofs : 1, sizeof(uint64_t));
+    int* col = (int*)malloc(sizeof(int) * (ncells > 0 ? ncells : 1));
+    int nc = 0, ok = 1;
+    for (int c = 0; c < ncells && ok; ++c)
+    {
+      const int32_t* dm = dofmap + (size_t)c * l->N;
+      uint64_t m = 0;
+      for (int t = 0; t < l->N; ++t)
+        m |= used[dm[t]];
+      int k = 0;
+      while (k < 64 && ((m >> k) & 1))
+        ++k;
+      if (k == 64)
+      {
+        ok = 0;
+        break;
+      }
+      col[c] = k;
+      if (k + 1 > nc)
+        nc = k + 1;
+      for (int t = 0; t < l->N; ++t)
+        used[dm[t]] |= (uint64_t)1 << k;
+    }
+    free(used);
+    if (ok)
+    {
+      l->ncolors = nc;
+      l->color_off = (int*)calloc(nc + 1, sizeof(int));
+      l->color_cells = (int*)malloc(sizeof(int) * (ncells > 0 ? ncells : 1));
+      for (int c = 0; c < ncells; ++c)
+        l->color_off[col[c] + 1]++;
+      for (int k = 0; k < nc; ++k)
+        l->color_off[k + 1] += l->color_off[k];
+      int* at = (int*)malloc(sizeof(int) * (nc > 0 ? nc : 1));
+      for (int k = 0; k < nc; ++k)
+        at[k] = l->color_off[k];
+      for (int c = 0; c < ncells; ++c)
+        l->color_cells[at[col[c]]++] = c;
+      free(at);
+    }
+    else
+      l->ncolors = 0; /* more than 64 colours: the scatter falls back to atomics */
+    free(col);
+  }
   return l;
 }
 
@@ -126,6 +179,8 @@ void orc_level_destroy(orc_level* l)
   if (l)
   {
     free(l->dinv);
+    free(l->color_off);
+    free(l->color_cells);
     free(l);
   }
 }
@@ -184,19 +239,41 @@ void orc_level_apply(const orc_level* l, const double* x, double* y)
 #pragma omp parallel
   {
     double u[ORC_MAXND * ORC_MAXND * ORC_MAXND], out[ORC_MAXND * ORC_MAXND * ORC_MAXND];
-#pragma omp for schedule(static)
-    for (int c = 0; c < l->ncells; ++c)
+    if (l->ncolors > 0)
     {
-      const int32_t* dm = l->dofmap + (size_t)c * N;
-      for (int t = 0; t < N; ++t)
-        u[t] = l->bc[dm[t]] ? 0.0 : x[dm[t]]; /* :186-189 */
-      cell_kernel(l, c, u, out);
-      for (int t = 0; t < N; ++t)
+      /* colour by colour (implicit barrier between colours): plain adds */
+      for (int k = 0; k < l->ncolors; ++k)
       {
-        if (!l->bc[dm[t]])
+#pragma omp for schedule(static)
+        for (int i = l->color_off[k]; i < l->color_off[k + 1]; ++i)
         {
+          const int c = l->color_cells[i];
+          const int32_t* dm = l->dofmap + (size_t)c * N;
+          for (int t = 0; t < N; ++t)
+            u[t] = l->bc[dm[t]] ? 0.0 : x[dm[t]]; /* :186-189 */
+          cell_kernel(l, c, u, out);
+          for (int t = 0; t < N; ++t)
+            if (!l->bc[dm[t]])
+              y[dm[t]] += out[t]; /* :277 */
+        }
+      }
+    }
+    else
+    {
+#pragma omp for schedule(static)
+      for (int c = 0; c < l->ncells; ++c)
+      {
+        const int32_t* dm = l->dofmap + (size_t)c * N;
+        for (int t = 0; t < N; ++t)
+          u[t] = l->bc[dm[t]] ? 0.0 : x[dm[t]]; /* :186-189 */
+        cell_kernel(l, c, u, out);
+        for (int t = 0; t < N; ++t)
+        {
+          if (!l->bc[dm[t]])
+          {
 #pragma omp atomic
-          y[dm[t]] += out[t]; /* :277 */
+            y[dm[t]] += out[t]; /* :277 */
+          }
         }
       }
     }
@@ -362,21 +439,37 @@ void orc_restrict(const orc_interp* it, const double* fine, double* coarse)
 {
   const int Nc = it->Nc, Nf = it->Nf;
   memset(coarse, 0, sizeof(double) * it->lc->ndofs);
-#pragma omp parallel for schedule(static)
-  for (int c = 0; c < it->lf->ncells; ++c)
+  /* cells that share no fine dof share no coarse dof either (every shared vertex / edge / face carries
+   * dofs of both degrees): the fine level's colouring serves the coarse scatter */
+  const orc_level* lf = it->lf;
+  const int colored = lf->ncolors > 0;
+  const int nrounds = colored ? lf->ncolors : 1;
+#pragma omp parallel
+  for (int r = 0; r < nrounds; ++r)
   {
-    const int32_t* d1 = it->lc->dofmap + (size_t)c * Nc;
-    const int32_t* d2 = it->lf->dofmap + (size_t)c * Nf;
-    double uf[ORC_MAXND * ORC_MAXND * ORC_MAXND];
-    for (int k = 0; k < Nf; ++k)
-      uf[k] = fine[d2[k]] * it->inv_mult[d2[k]];
-    for (int j = 0; j < Nc; ++j)
+    const int i0 = colored ? lf->color_off[r] : 0, i1 = colored ? lf->color_off[r + 1] : lf->ncells;
+#pragma omp for schedule(static)
+    for (int i = i0; i < i1; ++i)
     {
-      double v = 0;
+      const int c = colored ? lf->color_cells[i] : i;
+      const int32_t* d1 = it->lc->dofmap + (size_t)c * Nc;
+      const int32_t* d2 = it->lf->dofmap + (size_t)c * Nf;
+      double uf[ORC_MAXND * ORC_MAXND * ORC_MAXND];
       for (int k = 0; k < Nf; ++k)
-        v += it->M[(size_t)k * Nc + j] * uf[k];
+        uf[k] = fine[d2[k]] * it->inv_mult[d2[k]];
+      for (int j = 0; j < Nc; ++j)
+      {
+        double v = 0;
+        for (int k = 0; k < Nf; ++k)
+          v += it->M[(size_t)k * Nc + j] * uf[k];
+        if (colored)
+          coarse[d1[j]] += v;
+        else
+        {
 #pragma omp atomic
-      coarse[d1[j]] += v;
+          coarse[d1[j]] += v;
+        }
+      }
     }
   }
 }

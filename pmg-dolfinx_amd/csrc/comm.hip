@@ -94,6 +94,7 @@ struct pmg_comm_s
   int rank = 0, nranks = 1;
   hipStream_t stream = nullptr; // every RCCL call of this communicator is issued here, in program order
   hipEvent_t ev_in = nullptr, ev_out = nullptr; // reductions: compute stream -> comm stream -> compute stream
+  bool reduced_eagerly = false; // an all-reduce has been issued outside a capture (see comm_capture_ready)
 };
 
 static_assert(sizeof(ncclUniqueId) == PMG_COMM_ID_BYTES, "pmg_comm id size");
@@ -167,6 +168,7 @@ extern "C" int pmg_layout_set_comm(pmg_layout l, pmg_comm comm, int32_t n_neighb
               "pmg_layout_set_comm: per-neighbour counts (%lld, %lld) do not add up to the layout's "
               "n_send, n_recv (%d, %d)", ns, nr, l->n_send, l->n_recv);
   l->comm = comm;
+  l->exchanged_eagerly = false;
   l->nb_rank.assign(neighbor_ranks, neighbor_ranks + n_neighbors);
   l->nb_send.assign(send_counts, send_counts + n_neighbors);
   l->nb_recv.assign(recv_counts, recv_counts + n_neighbors);
@@ -247,8 +249,25 @@ int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s)
   PMG_NCCL(r);
   PMG_NCCL(re);
   if (!inline_group)
+  {
     PMG_HIP(hipEventRecord(l->ev_arrived, c->stream));
+    l->exchanged_eagerly = true;
+  }
   return PMG_OK;
+}
+
+// May a cycle over this layout be captured into a graph now?  RCCL sets up the connection to a peer (and a
+// collective's channels) the first time it is used; that must not happen inside a stream capture.  So the first
+// exchange of every layout and the first all-reduce of a communicator are always issued eagerly -- a cycle is
+// captured from its second application on.  Every rank reaches the same decision: the flags follow the call
+// sequence, which is the same on all ranks of a partitioned problem.
+bool comm_capture_ready(pmg_layout l, bool with_allreduce)
+{
+  if (!l->comm)
+    return true;
+  if (!l->nb_rank.empty() && !l->exchanged_eagerly)
+    return false;
+  return !with_allreduce || l->comm->reduced_eagerly;
 }
 
 int comm_exchange_end(pmg_layout l, hipStream_t s)
@@ -276,6 +295,7 @@ int comm_allreduce(pmg_layout l, double* d_values, int n, bool max, hipStream_t 
                             c->stream));
   PMG_HIP(hipEventRecord(c->ev_out, c->stream));
   PMG_HIP(hipStreamWaitEvent(s, c->ev_out, 0));
+  c->reduced_eagerly = true;
   return PMG_OK;
 }
 } // namespace pmg

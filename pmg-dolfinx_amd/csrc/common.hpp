@@ -97,6 +97,7 @@ struct pmg_layout_s
   int32_t *send_pos = nullptr, *recv_pos = nullptr;
   std::vector<size_t> send_off, recv_off;
   bool exchange_inline = false; // the exchange in flight was issued on the compute stream (graph capture)
+  bool exchanged_eagerly = false; // an exchange of this layout has been issued outside a capture (comm_capture_ready)
   const int32_t* send_idx = nullptr;
   const int32_t* recv_idx = nullptr;
   double* send_buf = nullptr;
@@ -122,6 +123,7 @@ constexpr int RED_SLOTS = 8;
 int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s);
 int comm_exchange_end(pmg_layout l, hipStream_t s);
 int comm_allreduce(pmg_layout l, double* d_values, int n, bool max, hipStream_t s);
+bool comm_capture_ready(pmg_layout l, bool with_allreduce);
 
 // Profiling ranges (roctx, bound at run time; no-ops when libroctx64 is absent).  The reference
 // annotates each CG iteration (src/amd_gpu.hpp:236-252, src/cg.hpp:174,219); here every phase of

@@ -164,6 +164,9 @@ int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n,
 namespace
 {
 int mg_apply_graph(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStream_t s, bool* done);
+// every captured cycle holds the device pointers of the objects it was captured with: any change of
+// the multigrid's parts invalidates all of them
+void drop_graphs(pmg_multigrid mg);
 
 int alloc_vec(pmg_layout l, double** p)
 {
@@ -393,7 +396,9 @@ int cg_iterate(pmg_cg cg, const ApplyFn& A, const double* dinv, const PrecondFn*
   PMG_TRY(dot_host(l, p, r, &rnorm0, s)); // :163
   double rnorm = rnorm0;
   const double rtol2 = cg->rtol * cg->rtol;
-  if (!(rnorm0 > 0.0)) // r = 0 (or not finite): x already solves the system; :206 would divide by zero
+  if (!std::isfinite(rnorm0) || rnorm0 < 0.0) // a poisoned right-hand side / operator, or an indefinite preconditioner
+    return fail(PMG_ERR_NUMERIC, "CG: r . M^-1 r = %g at the start is not a non-negative finite number", rnorm0);
+  if (rnorm0 == 0.0) // r = 0: x already solves the system; :206 would divide by zero
   {
     if (iterations)
       *iterations = 0;
@@ -556,6 +561,7 @@ extern "C" int pmg_multigrid_set_coarse_solver(pmg_multigrid mg, pmg_cg coarse)
   PMG_REQUIRE(mg, "pmg_multigrid_set_coarse_solver: NULL argument");
   PMG_REQUIRE(!coarse || coarse->layout == mg->layouts[0],
               "pmg_multigrid_set_coarse_solver: the solver is not on the coarsest layout");
+  drop_graphs(mg);
   mg->coarse = coarse;
   mg->coarse_fn = nullptr;
   mg->coarse_amg = nullptr;
@@ -567,6 +573,7 @@ extern "C" int pmg_multigrid_set_coarse_amg(pmg_multigrid mg, pmg_amg amg)
   PMG_REQUIRE(mg, "pmg_multigrid_set_coarse_amg: NULL argument");
   PMG_REQUIRE(!amg || amg_layout(amg) == mg->layouts[0],
               "pmg_multigrid_set_coarse_amg: the solver is not on the coarsest layout");
+  drop_graphs(mg);
   mg->coarse_amg = amg;
   if (amg)
   {
@@ -579,6 +586,7 @@ extern "C" int pmg_multigrid_set_coarse_amg(pmg_multigrid mg, pmg_amg amg)
 extern "C" int pmg_multigrid_set_coarse_callback(pmg_multigrid mg, pmg_coarse_solve_fn solve, void* user)
 {
   PMG_REQUIRE(mg, "pmg_multigrid_set_coarse_callback: NULL argument");
+  drop_graphs(mg);
   mg->coarse_fn = solve;
   mg->coarse_user = user;
   if (solve)
@@ -612,6 +620,7 @@ extern "C" int pmg_multigrid_set_operators(pmg_multigrid mg, const pmg_laplacian
   for (int i = 0; i < mg->L; ++i)
     PMG_REQUIRE(ops[i] && laplacian_layout(ops[i]) == mg->layouts[i],
                 "pmg_multigrid_set_operators: level %d layout mismatch", i);
+  drop_graphs(mg);
   mg->ops.assign(ops, ops + mg->L);
   return PMG_OK;
 }
@@ -622,6 +631,7 @@ extern "C" int pmg_multigrid_set_solvers(pmg_multigrid mg, const pmg_chebyshev* 
   for (int i = 0; i < mg->L; ++i)
     PMG_REQUIRE(smoothers[i] && smoothers[i]->layout == mg->layouts[i],
                 "pmg_multigrid_set_solvers: level %d layout mismatch", i);
+  drop_graphs(mg);
   mg->smoothers.assign(smoothers, smoothers + mg->L);
   return PMG_OK;
 }
@@ -629,6 +639,7 @@ extern "C" int pmg_multigrid_set_solvers(pmg_multigrid mg, const pmg_chebyshev* 
 extern "C" int pmg_multigrid_set_interpolators(pmg_multigrid mg, const pmg_interpolator* interp)
 {
   PMG_REQUIRE(mg && (interp || mg->L == 1), "pmg_multigrid_set_interpolators: NULL argument");
+  drop_graphs(mg);
   mg->interps.clear();
   for (int i = 0; i < mg->L - 1; ++i)
   {
@@ -661,10 +672,21 @@ long long capture_config(pmg_multigrid mg)
     // capture crashes RCCL 2.26).
     if (l->exchange && !l->comm)
       return -1;
+    // first use of a peer connection / of the collective must not fall inside a capture: eager until every level's
+    // layout has exchanged once (and, with the replicated AMG's all-reduce, the communicator has reduced once)
+    if (!comm_capture_ready(l, i == 0 && mg->coarse_amg != nullptr))
+      return -1;
     const long long st = laplacian_capture_state(mg->ops[i]);
     if (st < 0)
       return -1;
     mix((uint64_t)st);
+    // identities: a graph replays the device pointers of the objects it was captured with (the setters drop the
+    // cache as well; this covers an object replaced by another one at the same address only by accident)
+    mix((uint64_t)(uintptr_t)mg->ops[i]);
+    mix((uint64_t)(uintptr_t)mg->smoothers[i]);
+    mix((uint64_t)(uintptr_t)l->comm);
+    if (i + 1 < mg->L)
+      mix((uint64_t)(uintptr_t)mg->interps[i]);
     mix((uint64_t)mg->smoothers[i]->max_iter);
     uint64_t bits;
     static_assert(sizeof(bits) == sizeof(double), "");
@@ -679,6 +701,7 @@ long long capture_config(pmg_multigrid mg)
     if (st < 0)
       return -1;
     mix((uint64_t)st);
+    mix((uint64_t)(uintptr_t)mg->coarse_amg);
   }
   return (long long)(h >> 1);
 }
@@ -688,7 +711,7 @@ long long capture_config(pmg_multigrid mg)
 int mg_apply_graph(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStream_t s, bool* done)
 {
   *done = false;
-  if ((int)mg->ops.size() != mg->L || (int)mg->smoothers.size() != mg->L)
+  if ((int)mg->ops.size() != mg->L || (int)mg->smoothers.size() != mg->L || (int)mg->interps.size() != mg->L - 1)
     return PMG_OK; // mg_apply reports it
   const long long cfg = capture_config(mg);
   if (cfg < 0)

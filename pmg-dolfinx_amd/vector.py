@@ -144,6 +144,10 @@ class RcclComm:
         c._host = TorchComm(group)  # set-up-time host exchanges (numpy arrays) only
         return c
 
+    def size(self) -> int:
+        """Ranks of the RCCL communicator itself (``pmg_comm_size``), not of the launcher's group."""
+        return int(_lib.lib().pmg_comm_size(self.native))
+
     def all_to_all_host(self, layout, send, recv_count):
         if self._host is None:
             raise RuntimeError("RcclComm without a host-side bootstrap group cannot move host arrays")

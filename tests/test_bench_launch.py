@@ -1,0 +1,82 @@
+"""bench.py's launch contract (the reference's run is `srun -n 8`, examples/pmg/submit.sh:29):
+`--gpus N` never yields a line for another number of ranks -- it starts its N ranks itself as child processes,
+or exits non-zero with a message.  CPU only: no GPU is touched."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(kw)
+    return env
+
+
+def _bench_module():
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _no_gpu_here():
+    import torch
+
+    return torch.cuda.device_count() == 0
+
+
+@pytest.mark.skipif(not _no_gpu_here(), reason="the refusal for missing devices is checked on the GPU-less box")
+def test_gpus_2_without_devices_is_refused_not_downgraded():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""  # no JSON line of a smaller run
+    assert "--gpus 2" in r.stderr and "refusing" in r.stderr
+
+
+def test_world_size_mismatch_is_an_error():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=_env(WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert "WORLD_SIZE=4" in r.stderr
+
+
+def test_self_launch_starts_the_ranks_as_children(monkeypatch):
+    """With enough devices and no launcher in the environment, `--gpus N` becomes ONE child process:
+    `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` on a free local port;
+    the parent never initialises a GPU and returns the launcher's exit code."""
+    b = _bench_module()
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(b, "visible_gpus", lambda: 4)
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", [BENCH, "--gpus", "4", "--steps", "2"])
+    args = b.parse_args(["--gpus", "4", "--steps", "2"])
+    assert b.self_launch(args) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    port = int(cmd[cmd.index("--master-port") + 1])
+    assert 1024 < port < 65536
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and os.path.samefile(cmd[-5], BENCH)
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+
+
+def test_self_launch_refuses_when_devices_are_short(monkeypatch):
+    b = _bench_module()
+    monkeypatch.setattr(b, "visible_gpus", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        b.self_launch(b.parse_args(["--gpus", "2"]))
+    assert e.value.code == 2

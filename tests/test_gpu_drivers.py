@@ -211,3 +211,20 @@ def test_pmg_driver_graph_replay(built, tmp_path):
         ref = run("pmg_main", "--n", 6, "--orders", "1,2,4", "--cycles", 2, *extra)
         (a,), (b,) = grab(r"Cycle 2: residual norm = (\S+)", out), grab(r"Cycle 2: residual norm = (\S+)", ref)
         assert abs(a - b) < 1e-10 * b  # atomic-order noise of the merged launches
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`bench.py --gpus N` on a box with fewer devices exits non-zero with a message and
+    prints no line (never a 1-rank measurement labelled N GPUs)."""
+    import subprocess
+    import sys
+
+    import torch
+
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2 and r.stdout.strip() == ""
+    assert f"--gpus {n}" in r.stderr and "refusing" in r.stderr

@@ -341,6 +341,86 @@ def test_vcycle_graph_replay(pm):
     h.mg.set_graph(False)
 
 
+def test_graph_cache_is_dropped_when_parts_are_swapped(pm):
+    """a captured cycle holds the device pointers of the operators / smoothers / transfers / coarse
+    solver it was captured with.  Swapping any of them with graph replay LEFT ENABLED must not replay the old
+    objects: every setter drops the cache (and the handles are part of the cache key)."""
+    h = pm.PoissonHierarchy(6, (1, 2, 4), kappa=2.0, cheb_its=3, warp=warp)
+    import torch
+
+    # the same levels with kappa = 3, on h's own layouts (set_operators checks the layout handles)
+    kappa3 = torch.full((h.part.ncells,), 3.0, dtype=torch.float64, device="cuda")
+    ops3 = []
+    for P, lv, lay in zip(h.orders, h.levels, h.layouts):
+        o = pm.MatFreeLaplacian(P, kappa3, lv.dofmap, h.xgeom, h.geom_dofmap, lv.lcells, lv.bcells, lv.bc_marker, lay)
+        o.compute_diag_inverse()
+        ops3.append(o)
+    b = h.rhs[-1]
+
+    def cycles(mg, k=2):
+        x = h.new_vector()
+        x.set(0.0)
+        for _ in range(k):
+            mg.apply(b, x)
+        return x.data_copy()
+
+    # references, all eager
+    e2 = cycles(h.mg)
+    amg1, amg2 = pm.AmgSolver(h.operators[0], cycles=1), pm.AmgSolver(ops3[0], cycles=1)
+    h.mg.set_coarse_solver(amg1)
+    e_amg1 = cycles(h.mg)
+    h.mg.set_coarse_solver(amg2)
+    e_amg2 = cycles(h.mg)
+    h.mg.set_coarse_solver(None)
+    assert _relerr(e_amg2, e_amg1) > 1e-6
+
+    h.mg.set_graph(True)
+    y = h.new_vector()
+
+    def replayed(k=2):  # same (rhs, y) pair every time: the cache key's vectors do not change
+        y.set(0.0)
+        for _ in range(k):
+            h.mg.apply(b, y)
+        return y.data_copy()
+
+    assert _relerr(replayed(), e2) < 1e-13
+    # swap the coarse AMG for one with the SAME parameters (so the same configuration hash but other matrices)
+    h.mg.set_coarse_solver(amg1)
+    assert _relerr(replayed(), e_amg1) < 1e-13
+    h.mg.set_coarse_solver(amg2)
+    assert _relerr(replayed(), e_amg2) < 1e-13
+    h.mg.set_coarse_solver(None)
+    # swap the operators (and with them smoothers' diagonals): kappa = 3 operators under the kappa = 2 multigrid
+    h.mg.set_graph(False)
+    h.mg.set_operators(ops3)
+    e3 = cycles(h.mg)
+    h.mg.set_operators(h.operators)
+    h.mg.set_graph(True)
+    assert _relerr(replayed(), e2) < 1e-13
+    h.mg.set_operators(ops3)
+    got = replayed()
+    assert _relerr(got, e3) < 1e-13 and _relerr(got, e2) > 1e-6
+    h.mg.set_operators(h.operators)
+    h.mg.set_graph(False)
+
+
+def test_cg_reports_a_poisoned_right_hand_side(pm):
+    """a NaN right-hand side is an error, not "already converged"."""
+    h = pm.PoissonHierarchy(4, (2,), kappa=2.0)
+    cg = pm.CGSolver(h.layouts[-1])
+    cg.set_max_iterations(5)
+    cg.set_tolerance(1e-8)
+    bad = h.new_vector()
+    bad.set(float("nan"))
+    x = h.new_vector()
+    x.set(0.0)
+    with pytest.raises(RuntimeError, match="not a non-negative finite"):
+        cg.solve(h.operators[-1], x, bad)
+    # zero right-hand side: converged at once, no error
+    bad.set(0.0)
+    assert cg.solve(h.operators[-1], x, bad) == 0
+
+
 def test_errors(pm):
     part = pm.BoxPartition(2)
     lv = part.level(1)

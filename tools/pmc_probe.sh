@@ -18,7 +18,12 @@ pass() { # name counters...
 pass sq_lds SQ_ACTIVE_INST_LDS SQ_INSTS_LDS &&
 pass ta_busy TA_TA_BUSY_sum &&
 pass ta_addr TA_ADDR_STALLED_BY_TC_CYCLES_sum &&
-pass ta_data TA_DATA_STALLED_BY_TC_CYCLES_sum &&
-pass ta_all TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum &&
-pass r1_group TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum SQ_ACTIVE_INST_LDS
+pass ta_data TA_DATA_STALLED_BY_TC_CYCLES_sum
+rc=$?
+# Known to fail (profiles/pmc_probe_r02.md): three TA *_sum counters in one pass make rocprofv3 abort with error
+# 38 and hang in its signal handler.  Only on explicit request, to re-check a new ROCm.
+if [ $rc -eq 0 ] && [ "${PMC_PROBE_KNOWN_BAD:-0}" = "1" ]; then
+  pass ta_all TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum &&
+  pass r1_group TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum SQ_ACTIVE_INST_LDS
+fi
 echo "done" | tee -a $OUT/summary.txt

@@ -42,10 +42,21 @@ out = {"note": "KB counters of rocprofv3 --pmc, per launch (mean over launches).
                "(known byte count) is therefore added back once; the remaining reads (4/8-byte gathers, "
                "uncalibrated widths) are taken at face value."}
 lines = ["| kernel | launches | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch |", "|---|---|---|---|"]
+for k in sorted(write):
+    if k not in fetch:
+        lines.append(f"| `{k.strip()[-60:]}` | {len(write[k])} | n/a (kernel absent from the fetch pass) | "
+                     f"{sum(write[k]) / len(write[k]):.0f} |")
 for k in sorted(fetch):
     fk = sum(fetch[k]) / len(fetch[k])
-    wk = sum(write.get(k, [0])) / max(len(write.get(k, [0])), 1)
+    if k not in write:  # the two passes must come from the same build (a renamed kernel has no partner): say so
+        lines.append(f"| `{k.strip()[-60:]}` | {len(fetch[k])} | {fk:.0f} | n/a (kernel absent from the write pass) |")
+        continue
+    wk = sum(write[k]) / len(write[k])
     lines.append(f"| `{k.strip()[-60:]}` | {len(fetch[k])} | {fk:.0f} | {wk:.0f} |")
+    # vector kernels: 16 B per lane streams both ways -- FETCH_SIZE at half its bytes, WRITE_SIZE exact
+    if k.strip().startswith("ew_kernel2<Cheb") and "<true" in k:
+        out.setdefault("vector_kernels_bytes_per_launch", {})[k.strip()] = {
+            "fetch_kb_raw": fk, "write_kb": wk, "hbm_bytes_corrected": (2 * fk + wk) * 1024}
     if "stiffness_column_kernel<4, false>" in k:
         raw = (fk + wk) * 1024
         corrected = raw + g_bytes / 2
