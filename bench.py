@@ -35,6 +35,22 @@ def algorithmic_bytes_per_cell(P: int) -> int:
     return 48 * N + 4 * N + 8 + 17 * U
 
 
+def cycle_algorithmic_bytes(orders, ncells, ndofs, k):
+    """Algorithmic bytes of one lean V-cycle: per level l > 0 2(k+1)+1 applies and 2(5+8k)+6 vector
+    passes, coarsest level k+1 applies and 5+8k passes, transfers = both dofmaps + fine and coarse vectors
+    (+ multiplicity in the restriction).  32.8 GB for config 2."""
+    total = 0.0
+    for i, (P, nd) in enumerate(zip(orders, ndofs)):
+        applies = (k + 1) if i == 0 else 2 * (k + 1) + 1
+        passes = (5 + 8 * k) if i == 0 else 2 * (5 + 8 * k) + 6
+        total += applies * algorithmic_bytes_per_cell(P) * ncells + passes * 8.0 * nd
+        if i > 0:
+            nf, nc = (P + 1) ** 3, (orders[i - 1] + 1) ** 3
+            maps = 4.0 * (nf + nc) * ncells
+            total += 2 * maps + 8.0 * (2 * nd + ndofs[i - 1]) + 8.0 * (2 * nd + ndofs[i - 1])
+    return total
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -582,6 +598,7 @@ def main():
                 if not args.no_cpu:
                     from oracle import c_oracle as co
 
+                    co.set_num_threads(co.cpu_share())
                     cl = co.CLevel(Ps, 2.0, lvs.dofmap, parts.xgeom, parts.geom_dofmap, lvs.bc_marker)
                     ref = cl.apply(uh)
                     err = float(np.abs(ys.data_copy() - ref).max() / np.abs(ref).max())
@@ -614,6 +631,11 @@ def main():
             from oracle import c_oracle as co
 
             t0 = time.time()
+            # threads = the cores this process may really use (affinity mask capped by the cgroup CPU quota): the GPU
+            # box reports 128-256 logical CPUs but grants a 16-CPU quota, and 128 OpenMP threads under that quota run
+            # 3x slower than 16 (gpurun_out/r3_cpu_probe.txt)
+            ncores = co.cpu_share()
+            co.set_num_threads(ncores)
             part = H.part
             cl = [co.CLevel(p, 2.0, part.level(p).dofmap, part.xgeom, part.geom_dofmap, part.level(p).bc_marker)
                   for p in orders]
@@ -639,8 +661,12 @@ def main():
             err = float(np.abs(got - xc).max() / np.abs(xc).max())
             out["cpu_baseline"] = {"value": fine_dofs_global / cpu_s, "unit": "DoF/s", "cores": co.num_threads(),
                                    "kind": "port",
+                                   "algorithmic_GBs": round(cycle_algorithmic_bytes(orders, part.ncells, [
+                                       part.level(p).ndofs for p in orders], args.cheb) / cpu_s / 1e9, 1),
+                                   "host_logical_cpus": os.cpu_count(),
                                    "sample": f"{ncpu} V-cycles of the same workload ({args.n}^3 hexes, "
-                                             f"{fine_dofs_global} fine dofs), C/OpenMP oracle, after 1 warm-up cycle"}
+                                             f"{fine_dofs_global} fine dofs), C/OpenMP oracle (cell-coloured scatter, no "
+                                             f"atomics) on the process's CPU quota, after 1 warm-up cycle"}
             out["parity"] = {f"gpu_vs_cpu_oracle_rel_err_after_{1 + ncpu}_cycles": err, "tolerance": 1e-10}
             if not err < 1e-10:
                 parity_failures.append(f"V-cycle: rel. err {err:.3e} vs the C oracle after {1 + ncpu} cycles")

@@ -51,6 +51,8 @@ def lib():
         L.orc_tqli.argtypes = [_dp, _dp, C.c_int]
         L.orc_tqli.restype = C.c_int
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads.restype = None
         L.orc_vcycle.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _dp, C.c_int] + [
             C.POINTER(_dp)
         ] * 5 + [_dp, _dp]
@@ -64,6 +66,31 @@ def _d(a):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def set_num_threads(n: int):
+    lib().orc_set_num_threads(int(n))
+
+
+def cpu_share() -> int:
+    """Host cores this process may really use: the affinity mask capped by the cgroup's CPU quota (a container
+    on a 128-thread host with a 16-CPU quota is throttled, not faster, with 128 OpenMP threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
 
 
 def tqli(d, e):

@@ -62,6 +62,16 @@ int orc_num_threads(void)
 #endif
 }
 
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+  if (n > 0)
+    omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 /* ---- geometry: src/laplacian.hpp:22-113 (detJ by full cofactor expansion) ---- */
 void orc_geometry(int ncells, int nq, const double* xgeom, const int32_t* geom_dofmap,
                   const double* dphi /* [3][nq][8] */, const double* w, double* G)
