@@ -161,11 +161,65 @@ __device__ inline void jacobian(const double* __restrict__ xgeom,
 //     the per-cell planes are short and misaligned: P = 2 (seven 144-byte pieces per load
 //     instruction otherwise), 765 -> 674 us at 128^3; slower at P = 1, 3, 4 (1485 -> 1524, 513 -> 549,
 //     458 -> 480 us), so only P = 2 uses it.
+//   ring (P >= RING_FROM, gring()): [patch][item group g][item j of the group][layer c][pair][cell of the item][a*nd+b],
+//     dense -- the (item, layer) blocks of one item group (a wavefront, or the two wavefronts that share a cell at
+//     P = 8) follow each other in the order the group consumes them, across its items.  The group streams them
+//     through a ring of LDS slots with LDS-direct loads (stiffness_ring_kernel below).
 __host__ __device__ constexpr bool gflat(int nd) { return nd == 3; } // P = 2 only
 __host__ __device__ constexpr int gcw(int nd) { return nd * nd <= 64 ? 64 / (nd * nd) : 1; }
 __host__ __device__ constexpr int gls(int nd) { return ((3 * gcw(nd) * nd * nd + 7) / 8) * 8; } // layer stride
+// ring kernel configuration per degree: item groups per workgroup, ring depth in (item, layer) blocks; depth 0 = the
+// degree runs on the column kernel with register-held G.  ALL degrees do: the ring kernel is parity-green (every
+// degree, both cell lists, odd meshes) and slower -- P = 5 / 6 / 7 / 8: 596 / 577 / 431 / 649 us against 536 / 511 /
+// 412 / 496 us for the column kernel (profiles/kernel_tuning_r03.md: the LDS-direct loads themselves cost the time,
+// not the waits; the cell loop is bound by the LDS pipe, which the ring loads further).  Kept as a build option
+// (-DPMG_RING_P8='{2,3}' ...) for the record of that measurement.
+struct RingCfg
+{
+  int groups, depth;
+};
+#ifndef PMG_RING_P4
+#define PMG_RING_P4 {0, 0}
+#endif
+#ifndef PMG_RING_P5
+#define PMG_RING_P5 {0, 0} // measured with {4, 3}: slower, see above
+#endif
+#ifndef PMG_RING_P6
+#define PMG_RING_P6 {0, 0} // measured with {4, 3}: slower, see above
+#endif
+#ifndef PMG_RING_P7
+#define PMG_RING_P7 {0, 0} // measured with {8, 2}: slower, see above
+#endif
+#ifndef PMG_RING_P8
+#define PMG_RING_P8 {0, 0} // measured with {2, 3}: slower, see above
+#endif
+__host__ __device__ constexpr RingCfg ring_cfg(int nd)
+{
+  switch (nd)
+  {
+  case 5:
+    return PMG_RING_P4;
+  case 6:
+    return PMG_RING_P5;
+  case 7:
+    return PMG_RING_P6;
+  case 8:
+    return PMG_RING_P7;
+  case 9:
+    return PMG_RING_P8;
+  default:
+    return {0, 0};
+  }
+}
+__host__ __device__ constexpr bool gring(int nd) { return ring_cfg(nd).depth > 0; }
+__host__ __device__ constexpr int ring_ipg(int nd, int K) // items per group
+{
+  return ((K + gcw(nd) - 1) / gcw(nd) + ring_cfg(nd).groups - 1) / (gring(nd) ? ring_cfg(nd).groups : 1);
+}
 __host__ __device__ constexpr long long gpatch(int nd, int K)
 {
+  if (gring(nd))
+    return (long long)ring_cfg(nd).groups * ring_ipg(nd, K) * nd * 3 * gcw(nd) * nd * nd;
   return gflat(nd) ? (long long)((K + gcw(nd) - 1) / gcw(nd)) * nd * gls(nd) : (long long)K * 3 * nd * nd * nd;
 }
 // absolute position of (patch slot, quadrature point q = (a,b,c), component pair)
@@ -173,6 +227,14 @@ __device__ __forceinline__ size_t gpos(int nd, int K, long long slot, int q, int
 {
   const int nsq = nd * nd, N = nsq * nd;
   const int a = q / nsq, b = (q - a * nsq) / nd, c = q - a * nsq - b * nd;
+  if (gring(nd))
+  {
+    const long long p = slot / K;
+    const int sl = (int)(slot - p * K), cw = gcw(nd), it = sl / cw, ci = sl - it * cw;
+    const int ng = ring_cfg(nd).groups, g = it % ng, j = it / ng, WL = cw * nsq;
+    return (size_t)p * gpatch(nd, K) + ((size_t)(g * ring_ipg(nd, K) + j) * nd + c) * (3 * WL) + pair * WL + ci * nsq
+           + a * nd + b;
+  }
   if (!gflat(nd))
     return (size_t)slot * 3 * N + (c * 3 + pair) * nsq + a * nd + b;
   const long long p = slot / K;
@@ -415,9 +477,14 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     {
       const uint32_t dof = m[k] & PD_MASK;
       const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+#ifdef PMG_ABL_NOGATHER
+      xv[k] = 1.0 + dof;
+      yv[k] = acc ? 1.0 : 0.0;
+#else
       xv[k] = x[dof];
       const double* ya = acc ? (const double*)(y + dof) : (x + dof);
       yv[k] = *ya;
+#endif
     }
     const double kapk = kappa[cellk >= 0 ? cellk : 0];
 #pragma unroll
@@ -607,6 +674,11 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   lds_barrier();
 
   // ---- write back (plain stores; the accumulator started from the earlier colours' y)
+#ifdef PMG_ABL_NOWB
+  if (sy[t % MAXM] == 1.2345e-300)
+    y[t] = 1.0;
+  return;
+#endif
 #pragma unroll
   for (int k = 0; k < ITER; ++k)
   {
@@ -632,6 +704,332 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     }
   }
 }
+// ---- the hot kernel, ring form (P >= 5: ring_cfg) ------------------------------------------
+//
+// The column kernel above holds ONE layer of G per wavefront in registers, so a compute unit has
+// 8 - 16 x 2.4 - 3.9 KB of the tensor in flight against the ~50 KB the stream needs
+// (profiles/kernel_resources_r02.md), and a deeper register pipeline spills.  Here the tensor does not
+// pass through registers on its way in: every item group (a wavefront; at P = 8 the two wavefronts that
+// share a cell) streams its (item, layer) blocks with LDS-direct loads (global_load_lds_dwordx4, 1 KB
+// per wave instruction, no destination registers) into a private ring of RD LDS slots, RD - 1 blocks
+// ahead of the layer it computes, across item boundaries, from the first instruction of the kernel
+// (so the first blocks arrive under the gather phase).  The blocks of a group are contiguous in memory
+// in the order of use (layout `ring`, gpos()).
+//
+// Ordering.  LDS-direct loads count on the wave's vector-memory counter in issue order.  They are issued
+// with inline assembly, which the compiler's wait insertion does not see -- deliberately: told about
+// them (the builtin), it drains the counter (vmcnt(0)) before every LDS read that might alias.  So
+//   * the cell loop contains no other vector-memory instruction (the patch position table is staged in
+//     LDS in phase 0, kappa and the 1-D table come from LDS / scalar loads), and the waits for the ring
+//     are written by hand: before layer n's values are read, `s_waitcnt vmcnt((blocks issued after n) x
+//     (pieces per block and wave))`; with two waves per cell the workgroup barrier of the slice
+//     hand-over follows, so the partner's pieces have landed too;
+//   * a slot is refilled (block n + RD) only after the layer's fluxes have been formed from its values
+//     and, with two waves per cell, after the barrier behind them: no LDS read of the old block can
+//     still be in flight when the new one lands;
+//   * waits the compiler places for its own loads in the gather phase count only its own loads; older
+//     LDS-direct loads make such a wait stricter (the counter retires in order), never weaker.
+typedef __attribute__((address_space(3))) char lds_char;
+#ifndef PMG_RING_NT
+#define PMG_RING_NT " nt"
+#endif
+__device__ __forceinline__ void lds_dma16s(const void* sbase, unsigned voff, unsigned lds_byte, unsigned long long lanes)
+{
+  // the lanes of `lanes` (never empty): 16 bytes from sbase + voff to LDS[lds_byte + 16 * lane].  Scalar base, 32-bit
+  // per-lane offset; EXEC and M0 are set and restored inside the statement, so no control flow reaches the compiler.
+  unsigned keep;
+  unsigned long long keepx;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %5\n\ts_mov_b64 exec, %4\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %2, %3" PMG_RING_NT "\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep), "=&s"(keepx)
+               : "v"(voff), "s"(sbase), "s"(lanes), "s"(lds_byte)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// the same for a count the optimiser folds after unrolling (an immediate in the instruction)
+__device__ __forceinline__ void wait_vmcnt_n(int n)
+{
+  switch (n)
+  {
+#define PMG_W(i)                                                                                   \
+  case i:                                                                                          \
+    wait_vmcnt<i>();                                                                               \
+    break;
+    PMG_W(0) PMG_W(1) PMG_W(2) PMG_W(3) PMG_W(4) PMG_W(5) PMG_W(6) PMG_W(7) PMG_W(8) PMG_W(9) PMG_W(10) PMG_W(11)
+    PMG_W(12) PMG_W(13) PMG_W(14) PMG_W(15) PMG_W(16) PMG_W(17) PMG_W(18) PMG_W(19) PMG_W(20) PMG_W(21) PMG_W(22)
+    PMG_W(23) PMG_W(24)
+#undef PMG_W
+  default:
+    wait_vmcnt<0>(); // stricter than asked for: always safe
+    break;
+  }
+}
+
+template <int P>
+struct RShape
+{
+  using Sh = Shape<P>;
+  static constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, MAXM = Sh::MAXM, NQ2 = Sh::NQ2, CW = Sh::CW, WPC = Sh::WPC;
+  static constexpr int ITEMS = Sh::ITEMS;
+  static constexpr int NG = ring_cfg(ND).groups > 0 ? ring_cfg(ND).groups : 1; // item groups per workgroup
+  static constexpr int RD = ring_cfg(ND).depth > 0 ? ring_cfg(ND).depth : 1;   // ring slots per group
+  static constexpr int NW = NG * WPC, THREADS = NW * 64;
+  static constexpr int ITER = (MAXM + THREADS - 1) / THREADS;
+  static constexpr int IPG = ring_ipg(ND, K);
+  static constexpr int WL = CW * NQ2, LB = 3 * WL;     // one (item, layer) block, in double2
+  static constexpr int NPIECE = (LB + 63) / 64;        // 1 KB wave instructions per block
+  static constexpr int NPW = NPIECE / WPC;             // ... per wave of the group
+  static_assert(NPIECE % WPC == 0, "the pieces of a block are dealt evenly to the waves of a group");
+  static_assert(RD <= ND, "the prefetch distance stays inside two items");
+  static_assert((RD - 1) * NPW < 64, "vmcnt range");
+  static_assert((K * N) % 2 == 0, "the position table is staged in 32-bit words");
+};
+#ifndef PMG_RING_MINWAVES
+#define PMG_RING_MINWAVES 2
+#endif
+#ifndef PMG_RING_MAXWAVES
+#define PMG_RING_MAXWAVES 2
+#endif
+template <int P>
+__global__ void __launch_bounds__(RShape<P>::THREADS)
+    __attribute__((amdgpu_waves_per_eu(PMG_RING_MINWAVES, PMG_RING_MAXWAVES)))
+    stiffness_ring_kernel(const double* __restrict__ x, double* __restrict__ y, const double2* __restrict__ G,
+                          const int32_t* __restrict__ poff, const uint32_t* __restrict__ pdofs,
+                          const int32_t* __restrict__ lmap_id, const uint16_t* __restrict__ lmaps,
+                          const int32_t* __restrict__ pcell, const int32_t* __restrict__ pncell,
+                          const double* __restrict__ kappa, const double* __restrict__ Dg, int first, int atomic_out)
+{
+  using R = RShape<P>;
+  constexpr int ND = R::ND, N = R::N, K = R::K, NQ2 = R::NQ2, CW = R::CW, NG = R::NG, WPC = R::WPC, RD = R::RD;
+  constexpr int MAXM = R::MAXM, THREADS = R::THREADS, ITER = R::ITER, WL = R::WL, LB = R::LB, NPIECE = R::NPIECE;
+  constexpr int NPW = R::NPW, IPG = R::IPG;
+  constexpr bool UNPAIRED = unpaired_slice_reads(P);
+  __shared__ double sD[ND * ND];
+  __shared__ double skap[K];
+  __shared__ double sx[MAXM];
+  __shared__ double sy[MAXM];
+  __shared__ double sq[NG * WL];
+  __shared__ double sgr[NG * WL];
+  __shared__ double sgs[NG * WL];
+  __shared__ uint32_t slm[K * N / 2];          // the patch's position table (uint16 pairs)
+  __shared__ double2 ring[NG * RD * LB];       // [group][slot][pair][cell of the item][column]
+
+  const int p = first + blockIdx.x;
+  const int t = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wv / WPC, h = wv - grp * WPC; // item group, wave inside the group
+  const int lane64 = t & 63;
+  const int nc = pncell[p];
+  // items of this group: grp, grp + NG, ...; with several waves per cell every group runs the same count
+  const int items_all = (nc + CW - 1) / CW;
+  const int nmy = __builtin_amdgcn_readfirstlane(WPC > 1 ? (items_all + NG - 1) / NG
+                                                         : (items_all > grp ? (items_all - grp + NG - 1) / NG : 0));
+  const double2* Gg = G + (size_t)p * gpatch(ND, K) + (size_t)grp * IPG * ND * LB; // the group's stream
+  const unsigned ring0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)&ring[grp * RD * LB]);
+  // block n of the stream -> ring slot n % RD (this wave's pieces of it)
+  const int NB = nmy * ND; // blocks of the group's stream
+  const unsigned voff = lane64 * 16;
+  auto issue = [&](int n, int slot) {
+    // Beyond the end of the stream: the same number of instructions, one lane each, re-reading the stream's first
+    // 16 bytes into the (free) slot -- the wait counts of the layer loop then need no special case at the tail.
+    // Everything is arithmetic on scalars: a branch inside the unrolled layer loop costs ~100 registers.
+    const unsigned long long rmask = 0ull - (unsigned long long)(n < NB);
+    const char* sb = reinterpret_cast<const char*>(Gg) + (((size_t)n * (LB * 16)) & rmask);
+    const unsigned dst = ring0 + (unsigned)slot * (LB * 16);
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+    {
+      const int pc = h + WPC * i; // this wave's i-th piece of the block
+      const int cnt = LB - pc * 64; // lanes of the piece (>= 1)
+      const unsigned long long full = cnt >= 64 ? ~0ull : ((1ull << (cnt & 63)) - 1ull);
+      lds_dma16s(sb + ((size_t)(pc * 1024) & rmask), voff, dst + pc * 1024, (full & rmask) | 1ull);
+    }
+  };
+  if (nmy > 0)
+  {
+#pragma unroll
+    for (int n = 0; n < RD; ++n)
+      issue(n, n); // RD <= ND <= blocks of the group
+  }
+
+  const int off = poff[p];
+  const int M = poff[p + 1] - off; // 1 <= M <= MAXM
+  const int table = lmap_id[p];
+
+  // ---- phase 0: gather (as in the column kernel) + the position table
+  {
+    uint32_t m[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+    {
+      const int i = t + k * THREADS;
+      m[k] = pdofs[off + (i < M ? i : M - 1)];
+    }
+    const int cellk = pcell[(size_t)p * K + (t < K ? t : K - 1)];
+    const double dval = Dg[t < ND * ND ? t : ND * ND - 1];
+    double xv[ITER], yv[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+    {
+      const uint32_t dof = m[k] & PD_MASK;
+      const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+      xv[k] = x[dof];
+      const double* ya = acc ? (const double*)(y + dof) : (x + dof);
+      yv[k] = *ya;
+    }
+    const double kapk = kappa[cellk >= 0 ? cellk : 0];
+    const uint32_t* lmw = reinterpret_cast<const uint32_t*>(lmaps + (size_t)table * (K * N));
+    constexpr int LMW = K * N / 2, LMI = (LMW + THREADS - 1) / THREADS;
+    uint32_t lmv[LMI];
+#pragma unroll
+    for (int k = 0; k < LMI; ++k)
+      lmv[k] = lmw[t + k * THREADS < LMW ? t + k * THREADS : LMW - 1];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+    {
+      const int i = t + k * THREADS;
+      if (i < M)
+      {
+        const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+        sx[i] = (m[k] & PD_BC) ? 0.0 : xv[k]; // src/laplacian.hpp:186-189
+        sy[i] = acc ? yv[k] : 0.0;
+      }
+    }
+    if (t < ND * ND)
+      sD[t] = dval;
+    for (int i = t; i < K; i += THREADS)
+      skap[i] = (i == t) ? kapk : kappa[pcell[(size_t)p * K + i] >= 0 ? pcell[(size_t)p * K + i] : 0];
+#pragma unroll
+    for (int k = 0; k < LMI; ++k)
+      if (t + k * THREADS < LMW)
+        slm[t + k * THREADS] = lmv[k];
+  }
+  lds_barrier();
+
+  // ---- cell loop
+  const int lane = lane64 + 64 * h;
+  const bool lane_ok = lane < WL;
+  const int lw = lane_ok ? lane : WL - 1;
+  const int cw = lw / NQ2;
+  const int ab = lw - cw * NQ2;
+  const int a = ab / ND, b = ab - a * ND;
+  double Da[ND], Db[ND], DTa[ND], DTb[ND]; // D[a][.], D[b][.], D[.][a], D[.][b]
+#pragma unroll
+  for (int mm = 0; mm < ND; ++mm)
+  {
+    Da[mm] = sD[a * ND + mm];
+    Db[mm] = sD[b * ND + mm];
+    DTa[mm] = sD[mm * ND + a];
+    DTb[mm] = sD[mm * ND + b];
+  }
+  double* q_s = sq + grp * WL + cw * NQ2;
+  double* gr_s = sgr + grp * WL + cw * NQ2;
+  double* gs_s = sgs + grp * WL + cw * NQ2;
+  const uint16_t* slm16 = reinterpret_cast<const uint16_t*>(slm);
+  const double2* ringg = ring + grp * RD * LB;
+  auto slice_sync = [] {
+    if constexpr (WPC > 1)
+      lds_barrier();
+    else
+      wave_fence();
+  };
+
+  int slot0 = 0; // ring slot of the item's first layer: (j * ND) % RD
+  for (int j = 0; j < nmy; ++j)
+  {
+    const int it = grp + j * NG;
+    const int slot = it * CW + cw;
+    const int slotc = slot < K ? slot : K - 1;
+    int l[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+      l[k] = slm16[slotc * N + k * NQ2 + ab];
+    const double kap = skap[slotc];
+    double u[ND], Aq[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+    {
+      u[k] = sx[l[k]];
+      Aq[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+    {
+      // block n = j * ND + k has landed once at most the blocks issued after it are outstanding
+#ifndef PMG_ABL_NOWAIT
+      wait_vmcnt<(RD - 1) * NPW>();
+#endif
+      const int sk = (slot0 + k) % RD;
+      q_s[ab] = u[k];
+      slice_sync();
+      const double2* rs = ringg + sk * LB + lw;
+      const double2 g01 = rs[0], g23 = rs[WL], g45 = rs[2 * WL];
+      double qr = 0.0, qs = 0.0, qt = 0.0;
+#pragma unroll
+      for (int mm = 0; mm < ND; ++mm)
+      {
+        qr += Da[mm] * slice_load<UNPAIRED>(q_s[mm * ND + b]); // d/dx, src/laplacian.hpp:195-199
+        qs += Db[mm] * slice_load<UNPAIRED>(q_s[a * ND + mm]); // d/dy, :206-210
+        qt += Dg[k * ND + mm] * u[mm];                         // d/dz, :214-218
+      }
+      const double fr = kap * (g01.x * qr + g01.y * qs + g23.x * qt); // :233
+      const double fs = kap * (g01.y * qr + g23.y * qs + g45.x * qt); // :234
+      const double ft = kap * (g23.x * qr + g45.x * qs + g45.y * qt); // :235
+      gr_s[ab] = fr;
+      gs_s[ab] = fs;
+      slice_sync();
+      // the slot is free (its values are in the fluxes; with two waves per cell the barrier above has seen
+      // the partner's as well): refill it with block n + RD
+#ifndef PMG_ABL_NODMA
+      issue(j * ND + k + RD, sk);
+#endif
+      double acc = 0.0;
+#pragma unroll
+      for (int mm = 0; mm < ND; ++mm)
+      {
+        acc += DTa[mm] * slice_load<UNPAIRED>(gr_s[mm * ND + b]); // :246-251
+        acc += DTb[mm] * slice_load<UNPAIRED>(gs_s[a * ND + mm]); // :255-259
+        Aq[mm] += Dg[k * ND + mm] * ft;                           // :263-267
+      }
+      Aq[k] += acc;
+      slice_sync();
+    }
+    const bool contributes = lane_ok && slot < nc;
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+      atomicAdd(&sy[l[k]], contributes ? Aq[k] : 0.0); // :270,277 -- in LDS (ds_add_f64)
+    slot0 = (slot0 + ND) % RD;
+  }
+  lds_barrier();
+
+  // ---- write back
+#pragma unroll
+  for (int k = 0; k < ITER; ++k)
+  {
+    const int i = t + k * THREADS;
+    if (i < M)
+    {
+      const uint32_t mk = pdofs[off + i];
+      const uint32_t dof = mk & PD_MASK;
+      if (mk & PD_BC)
+      {
+        if (!(mk & PD_ACC))
+          y[dof] = x[dof]; // :273-274
+      }
+      else if (atomic_out)
+        atomicAdd(&y[dof], sy[i]);
+      else
+        __builtin_nontemporal_store(sy[i], &y[dof]);
+    }
+  }
+}
+
 __global__ void zero_list_kernel(int n, const int32_t* __restrict__ idx, double* __restrict__ y)
 {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -756,6 +1154,17 @@ int launch_stiffness(pmg_laplacian op, const double* x, double* y, int first, in
   if (op->batch_patches > 0 && op->geometry_mode == 0)
     G = batch_geometry(op, first, count, s); // :391-396
   {
+    if constexpr (gring(P + 1))
+    {
+      if (op->geometry_mode != 1)
+      {
+        stiffness_ring_kernel<P><<<count, RShape<P>::THREADS, 0, s>>>(x, y, G, op->poff, op->pdofs, op->lmap_id, op->lmaps,
+                                                                   op->pcell, op->pncell, op->kappa, op->D, first,
+                                                                   atomic_out);
+        op->launches++;
+        return PMG_OK;
+      }
+    }
     if (op->geometry_mode == 1)
       stiffness_column_kernel<P, true><<<count, Shape<P>::WTHREADS, 0, s>>>(
           x, y, G, op->Gaff, op->W1, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell,
