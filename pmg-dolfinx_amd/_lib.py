@@ -81,6 +81,8 @@ _SIGS = {
     "pmg_laplacian_set_geometry_mode": (C.c_int, [vp, C.c_int]),
     "pmg_laplacian_launches_per_apply": (C.c_int, [vp]),
     "pmg_set_merge_threshold": (C.c_int, [C.c_longlong]),
+    "pmg_set_pipelined_apply": (C.c_int, [C.c_int]),
+    "pmg_laplacian_check": (C.c_int, [vp, vp]),
     "pmg_laplacian_set_profiling": (C.c_int, [vp, C.c_int]),
     "pmg_laplacian_read_profile": (C.c_int, [vp, c_dp, C.POINTER(C.c_longlong)]),
     "pmg_laplacian_time_kernel": (C.c_int, [vp, vp, vp, C.c_int, c_dp, vp]),

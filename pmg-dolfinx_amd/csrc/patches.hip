@@ -96,10 +96,17 @@ void group_cells(const int32_t* cells, int32_t n, const float* centroid, PatchSh
   if (tensor)
   {
     // sort by (block key, position inside the block); equal keys form a patch
+    // blocks of at most (bx, by, bz) cells, balanced: ceil(n / b) blocks per axis whose sizes differ by at most
+    // one (64 cells in blocks of at most 7: four of 7 and six of 6, not nine of 7 and one of 1)
+    const int bmax[3] = {shp.bx, shp.by, shp.bz};
+    int nblk[3];
+    for (int a = 0; a < 3; ++a)
+      nblk[a] = (ncl[a] + bmax[a] - 1) / bmax[a];
+    auto block = [&](int a, int32_t g) { return (uint64_t)(((long long)g * nblk[a]) / ncl[a]); };
     std::vector<uint64_t> key(n);
     for (int32_t i = 0; i < n; ++i)
     {
-      uint64_t bx = gi[0][i] / shp.bx, by = gi[1][i] / shp.by, bz = gi[2][i] / shp.bz;
+      uint64_t bx = block(0, gi[0][i]), by = block(1, gi[1][i]), bz = block(2, gi[2][i]);
       key[i] = (bx << 42) | (by << 21) | bz;
     }
     std::sort(order.begin(), order.end(),
