@@ -158,6 +158,62 @@ int main()
       CHECK(throws([&] { acc::norm(w, acc::Norm::linf); }, "allreduce_max"));
     }
 
+    // The library's RCCL communicator with this rank as its own neighbour: a forward scatter captured into a hipGraph
+    // (on a HIP >= 7.2 runtime the communicator's stream is forked into the capture, so the exchange stays a parallel
+    // branch: pmg_comm_capture_overlaps) must reproduce the eager one, replay after replay.
+    {
+      auto comm = std::make_shared<const Communicator>(0, 1, Communicator::unique_id());
+      const std::int32_t nb[1] = {0}, cnt[1] = {m};
+      auto cmap = std::make_shared<IndexMap>(n, m, send, recv, comm, nb, cnt, cnt);
+      DeviceVector xe(cmap, 1), xg(cmap, 1), w(cmap, 1);
+      xe.copy_from_host(a);
+      xg.copy_from_host(a);
+      w.copy_from_host(b);
+      xe.scatter_fwd_begin(); // eager first: peer connections are set up outside any capture
+      xe.scatter_fwd_end();
+      hipStream_t cs;
+      bool hip_ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+      hip_ok = hip_ok && hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) == hipSuccess;
+      bool lib_ok = pmg_scatter_fwd_begin(cmap->layout(), xg.mutable_array().data(), (pmg_stream)cs) == PMG_OK;
+      lib_ok = lib_ok && pmg_vec_scale(cmap->layout(), w.mutable_array().data(), 2.0, (pmg_stream)cs) == PMG_OK; // "interior work"
+      lib_ok = lib_ok && pmg_scatter_fwd_end(cmap->layout(), xg.mutable_array().data(), (pmg_stream)cs) == PMG_OK;
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      hip_ok = hip_ok && hipStreamEndCapture(cs, &graph) == hipSuccess && graph != nullptr;
+      hip_ok = hip_ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      CHECK(hip_ok && lib_ok);
+      if (hip_ok && lib_ok)
+      {
+        for (int rep = 0; rep < 3; ++rep)
+        {
+          std::vector<double> mod(a);
+          for (int j = 0; j < m; ++j)
+            mod[send[j]] = a[send[j]] + rep; // new owner values every replay
+          xg.copy_from_host(mod);
+          CHECK(hipDeviceSynchronize() == hipSuccess);
+          CHECK(hipGraphLaunch(exec, cs) == hipSuccess);
+          CHECK(hipStreamSynchronize(cs) == hipSuccess);
+          std::vector<double> gg = xg.data_copy();
+          bool same = true;
+          for (int j = 0; j < m; ++j)
+            same = same && gg[n + j] == mod[send[j]];
+          CHECK(same);
+        }
+        std::vector<double> ge = xe.data_copy();
+        bool eager_ok = true;
+        for (int j = 0; j < m; ++j)
+          eager_ok = eager_ok && ge[n + j] == a[send[j]];
+        CHECK(eager_ok);
+        std::printf("captured exchange: %s\n", pmg_comm_capture_overlaps() ? "communicator stream forked into the capture"
+                                                                            : "issued on the capturing stream");
+      }
+      if (exec)
+        (void)hipGraphExecDestroy(exec);
+      if (graph)
+        (void)hipGraphDestroy(graph);
+      (void)hipStreamDestroy(cs);
+    }
+
     // compute_boundary_cells: 4 cells of 2 dofs, 3 owned cells, 5 owned dofs
     std::vector<std::int32_t> dm = {0, 1, 2, 5, 3, 4, 0, 1};
     auto [lc, bc] = compute_boundary_cells(dm, 3, 4, 2, 5);

@@ -125,6 +125,10 @@ int pmg_layout_set_allreduce_max(pmg_layout l, pmg_allreduce_fn allreduce_max);
 int pmg_comm_unique_id(char* id /* [PMG_COMM_ID_BYTES] */);
 int pmg_comm_create(pmg_comm* out, int rank, int nranks, const char* id);
 int pmg_comm_destroy(pmg_comm comm);
+/* 1 if a halo exchange captured into a hipGraph keeps its overlap with the interior cells (the communicator's stream is
+ * forked into the capture), 0 if this process's HIP runtime cannot end such a capture (7.0.x: unbounded recursion in
+ * hipStreamEndCapture) and the captured exchange is issued on the capturing stream instead. */
+int pmg_comm_capture_overlaps(void);
 int pmg_comm_rank(pmg_comm comm);
 int pmg_comm_size(pmg_comm comm);
 int pmg_layout_set_comm(pmg_layout l, pmg_comm comm, int32_t n_neighbors, const int32_t* neighbor_ranks,
@@ -240,16 +244,6 @@ long long pmg_laplacian_geometry_bytes(pmg_laplacian op);
  * for tests and tuning. */
 int pmg_laplacian_launches_per_apply(pmg_laplacian op);
 int pmg_set_merge_threshold(long long patch_dofs);
-
-/* The degree-4 operator (stored geometry, not batched) runs its large launches on a persistent, phase-overlapped
- * kernel: one workgroup per CU whose compute waves go from patch to patch while two helper waves gather the next patch
- * and write the previous one back (csrc/laplacian.hip, stiffness_pipe_kernel).  pmg_set_pipelined_apply(0) sends
- * every launch to the one-workgroup-per-patch kernel instead, (2) every launch however small to the persistent one
- * (tests, measurements); process-wide, default 1 = launches with at least two patches per CU.
- * The waits inside that kernel are bounded: pmg_laplacian_check synchronises the stream and reports if one ever
- * gave up (no reference counterpart: src/laplacian.hpp has no intra-kernel hand-offs). */
-int pmg_set_pipelined_apply(int enable);
-int pmg_laplacian_check(pmg_laplacian op, pmg_stream stream);
 /* Dominant-kernel timing hook for bench.py: enqueue `reps` times every
  * stiffness-kernel launch of one operator application (no halo, no zero-fill)
  * bracketed by HIP events on `stream`; returns the mean milliseconds per launch

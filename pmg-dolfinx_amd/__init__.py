@@ -9,7 +9,7 @@ from .amg import AmgSolver  # noqa: F401
 from .cg import CGSolver  # noqa: F401
 from .chebyshev import Chebyshev  # noqa: F401
 from .interpolate import Interpolator  # noqa: F401
-from .laplacian import MatFreeLaplacian, set_merge_threshold, set_pipelined_apply  # noqa: F401
+from .laplacian import MatFreeLaplacian, set_merge_threshold  # noqa: F401
 from .mesh import BoxPartition, default_proc_dims  # noqa: F401
 from .pmg import MultigridPreconditioner  # noqa: F401
 from .problem import PoissonHierarchy, make_layout  # noqa: F401

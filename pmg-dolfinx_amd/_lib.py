@@ -45,6 +45,7 @@ _SIGS = {
     "pmg_comm_unique_id": (C.c_int, [C.c_char_p]),
     "pmg_comm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p]),
     "pmg_comm_destroy": (C.c_int, [vp]),
+    "pmg_comm_capture_overlaps": (C.c_int, []),
     "pmg_comm_rank": (C.c_int, [vp]),
     "pmg_comm_size": (C.c_int, [vp]),
     "pmg_layout_set_comm": (C.c_int, [vp, vp, C.c_int32, c_ip, c_ip, c_ip]),
@@ -81,8 +82,6 @@ _SIGS = {
     "pmg_laplacian_set_geometry_mode": (C.c_int, [vp, C.c_int]),
     "pmg_laplacian_launches_per_apply": (C.c_int, [vp]),
     "pmg_set_merge_threshold": (C.c_int, [C.c_longlong]),
-    "pmg_set_pipelined_apply": (C.c_int, [C.c_int]),
-    "pmg_laplacian_check": (C.c_int, [vp, vp]),
     "pmg_laplacian_set_profiling": (C.c_int, [vp, C.c_int]),
     "pmg_laplacian_read_profile": (C.c_int, [vp, c_dp, C.POINTER(C.c_longlong)]),
     "pmg_laplacian_time_kernel": (C.c_int, [vp, vp, vp, C.c_int, c_dp, vp]),
@@ -141,7 +140,7 @@ _SIGS = {
 }
 
 # functions whose int return value is a count, not a status
-_COUNT_FUNCS = {"pmg_multigrid_graph_replays", "pmg_amg_num_levels", "pmg_laplacian_geometry_bytes", "pmg_comm_rank", "pmg_comm_size", "pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
+_COUNT_FUNCS = {"pmg_multigrid_graph_replays", "pmg_amg_num_levels", "pmg_laplacian_geometry_bytes", "pmg_comm_rank", "pmg_comm_size", "pmg_comm_capture_overlaps", "pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
                 "pmg_laplacian_degree", "pmg_laplacian_launches_per_apply", "pmg_laplacian_is_affine"}
 
 _lib = None

@@ -24,6 +24,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 using namespace pmg;
@@ -206,6 +207,31 @@ extern "C" int pmg_layout_set_comm(pmg_layout l, pmg_comm comm, int32_t n_neighb
   return PMG_OK;
 }
 
+namespace
+{
+// May the communicator's stream be forked into a stream capture?  The HIP 7.0 runtime (the copy PyTorch 2.10+rocm7.0
+// bundles and a Python process therefore runs on) recurses without end in hip::Stream::EndCapture when the capture
+// holds a forked stream on which RCCL enqueued (RCCL forks its own stream from it again): a stack overflow at
+// hipStreamEndCapture, 174 000 frames deep (gpurun_out / profiles/rccl_capture_probe_r03.md).  The 7.2 runtime ends the
+// same capture correctly.  PMG_CAPTURE_FORK=0/1 overrides.
+bool capture_fork_supported()
+{
+  static int cached = -1;
+  if (cached < 0)
+  {
+    int v = 0;
+    if (hipRuntimeGetVersion(&v) != hipSuccess)
+      v = 0;
+    cached = v >= 70200000 ? 1 : 0; // HIP_VERSION = major * 10^7 + minor * 10^5 + patch
+    if (const char* e = std::getenv("PMG_CAPTURE_FORK"))
+      cached = (e[0] == '1') ? 1 : 0;
+  }
+  return cached == 1;
+}
+} // namespace
+
+extern "C" int pmg_comm_capture_overlaps(void) { return capture_fork_supported() ? 1 : 0; }
+
 namespace pmg
 {
 // One grouped neighbour exchange on the communicator's stream, ordered behind everything enqueued
@@ -216,13 +242,14 @@ int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s)
   pmg_comm c = l->comm;
   if (l->nb_rank.empty()) // no partner: nothing to post (point-to-point groups are not collectives)
     return PMG_OK;
-  // While `s` is being captured into a graph the group is issued on `s` itself (RCCL captures its kernels into
-  // the graph; forking to the communicator's stream inside a capture crashes RCCL 2.26): the replayed cycle costs
-  // the host one hipGraphLaunch instead of ~115 us per exchange, at the price of the overlap with the interior
-  // cells -- the trade for a strong-scaled level, where the host is the bound.
+  // While `s` is being captured into a graph the replayed cycle costs the host one hipGraphLaunch instead of
+  // ~115 us per exchange.  On a runtime whose capture can take it (capture_fork_supported) the communicator's
+  // stream is forked into the capture exactly as in the eager path -- event on `s`, wait on the communicator's stream,
+  // group, event, and the join in comm_exchange_end -- so the exchange is a parallel branch of the graph and still
+  // overlaps the interior cells.  Otherwise the group is issued on `s` itself: correct, no overlap.
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   PMG_HIP(hipStreamIsCapturing(s, &cap));
-  const bool inline_group = cap == hipStreamCaptureStatusActive;
+  const bool inline_group = cap == hipStreamCaptureStatusActive && !capture_fork_supported();
   hipStream_t cs = inline_group ? s : c->stream;
   l->exchange_inline = inline_group;
   if (!inline_group)
@@ -251,7 +278,8 @@ int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s)
   if (!inline_group)
   {
     PMG_HIP(hipEventRecord(l->ev_arrived, c->stream));
-    l->exchanged_eagerly = true;
+    if (cap != hipStreamCaptureStatusActive)
+      l->exchanged_eagerly = true;
   }
   return PMG_OK;
 }

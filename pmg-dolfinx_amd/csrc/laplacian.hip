@@ -76,8 +76,6 @@ struct pmg_laplacian_s
   int n_launch_l = 0;
   int n_plain = 0;
   bool needs_zero = false; // some local dof belongs to no listed cell
-  int* pipe_err = nullptr; // device word: a bounded wait of the pipelined kernel gave up (0 = never)
-  int num_cus = 0;
   double* diag_inv = nullptr; // [size_local + num_ghosts]
   bool have_diag = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -93,12 +91,6 @@ struct pmg_laplacian_s
   long long prof_launches = 0;
 };
 
-namespace pmg
-{
-// pmg_set_pipelined_apply: the persistent, phase-overlapped kernel where it exists (P = 4).
-// 0 = never, 1 = for launches that give every workgroup at least two patches, 2 = for every launch (tests)
-int g_pipeline = 1;
-}
 namespace
 {
 template <int P>
@@ -116,7 +108,7 @@ struct Shape
   static constexpr int ITEMS = (K + CW - 1) / CW;  // wave-items per full patch
   // measured (profiles/kernel_roofline_r01.md, profiles/kernel_tuning_r02.md): 4 waves and more
   // workgroups per CU for the register-heavy degrees and P = 3, 8 waves otherwise
-  static constexpr int NWMAX = (P == 3 || P == 5 || P == 6 || P == 8) ? 4 : (P == 4 && ITEMS == 12 ? 6 : 8);
+  static constexpr int NWMAX = (P == 3 || P == 5 || P == 6 || P == 8) ? 4 : 8;
   static constexpr int NG = ITEMS < NWMAX / WPC ? ITEMS : NWMAX / WPC; // items in flight per workgroup
   static constexpr int NW = NG * WPC;                                  // waves per workgroup
   static constexpr int WTHREADS = NW * 64;
@@ -1038,374 +1030,6 @@ __global__ void __launch_bounds__(RShape<P>::THREADS)
   }
 }
 
-// ---- the hot kernel, pipelined form (P = 4) ---------------------------------------------------------
-//
-// In the column kernel a workgroup is a serial chain gather -> cells -> write-back, and while it gathers or
-// writes back its waves only wait; with two workgroups per CU those phases (9.4 of 23 us) are covered by at
-// most one other workgroup.  Measured (profiles/kernel_tuning_r03.md): 462 us per application, 339 us with the
-// gather's and the write-back's memory traffic removed.  Here ONE persistent workgroup per CU walks through its
-// share of the launch's patches with the phases of consecutive patches overlapped:
-//   * NCW compute waves run the cell loop and nothing else: one item each per patch, straight from patch i to
-//     patch i + 1 (the patch arrays are double-buffered in LDS);
-//   * a gather wave loads x of patch i + 1 while the cells of patch i are computed and fills the other buffer as soon
-//     as it is free; a write-back wave adds the finished sums to the earlier colours' y (loaded in advance) and
-//     stores them.  Only the write-back wave ever stores: the vector-memory counter retires in order, so a wave that
-//     both stored and loaded would wait for its stores' acknowledgements (~4 us) before every gather (measured: with
-//     two helpers that each did both, 575 us per application).  Hand-offs, per buffer: `ready` (gather -> compute
-//     waves), `done` (compute waves -> write-back), `freed` (write-back -> gather).
-// The hand-offs are counters in LDS.  The LDS executes a wave's instructions in order and is the single point of
-// coherence of the workgroup, so a counter updated after the data in program order is seen after the data; there is
-// no s_barrier after the first one.  Every wait is bounded: a counter that does not arrive within ~30 ms sets the
-// operator's error word and the wave leaves the kernel (pmg_laplacian_check reports it).
-template <int P>
-struct PShape
-{
-  using Sh = Shape<P>;
-  static constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, MAXM = Sh::MAXM, NQ2 = Sh::NQ2, CW = Sh::CW;
-  static constexpr int NCW = Sh::ITEMS; // compute waves: one item of every patch each
-  static constexpr int NHR = 2;         // helper waves per role (gather, write-back): each owns 1 / NHR of the entries
-#ifndef PMG_PIPE_NB
-#define PMG_PIPE_NB 3
-#endif
-  static constexpr int NB = PMG_PIPE_NB; // patch buffers
-  static constexpr int NW = NCW + 2 * NHR, THREADS = NW * 64;
-  static constexpr int HL = 64 * NHR;                 // lanes of a role
-  static constexpr int HITER = (MAXM + HL - 1) / HL;  // patch entries per helper lane
-  static constexpr int WL = CW * NQ2;
-  static constexpr bool OK = Sh::WPC == 1 && NW <= 16 && K % CW == 0; // one wave per item, one workgroup
-};
-constexpr bool pipelined(int P) { return P == 4; }
-constexpr unsigned PIPE_SPIN_LIMIT = 1u << 18;
-
-typedef __attribute__((address_space(3))) volatile unsigned lds_vuint;
-// wait until the LDS counter reaches `target`; false (and the error word set) if it does not
-__device__ __forceinline__ bool pipe_wait(unsigned* counter, unsigned target, int* err, int code)
-{
-  for (unsigned it = 0; it < PIPE_SPIN_LIMIT; ++it)
-  {
-    const unsigned v = __builtin_amdgcn_readfirstlane(*(lds_vuint*)counter);
-    if (v >= target)
-    {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      return true;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-  if ((threadIdx.x & 63) == 0)
-    atomicCAS(err, 0, code);
-  return false;
-}
-__device__ __forceinline__ void pipe_signal(unsigned* counter)
-{
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if ((threadIdx.x & 63) == 0)
-    atomicAdd(counter, 1u); // ds_add_u32, behind this wave's earlier LDS traffic
-}
-
-template <int P>
-__global__ void __launch_bounds__(PShape<P>::THREADS, 1)
-    stiffness_pipe_kernel(const double* __restrict__ x, double* __restrict__ y, const double2* __restrict__ G,
-                          const int32_t* __restrict__ poff, const uint32_t* __restrict__ pdofs,
-                          const int32_t* __restrict__ lmap_id, const uint16_t* __restrict__ lmaps,
-                          const int32_t* __restrict__ pcell, const int32_t* __restrict__ pncell,
-                          const double* __restrict__ kappa, const double* __restrict__ Dg, int first, int count,
-                          int atomic_out, int* __restrict__ err)
-{
-  using S = PShape<P>;
-  constexpr int ND = S::ND, N = S::N, K = S::K, NQ2 = S::NQ2, CW = S::CW, NCW = S::NCW, NHR = S::NHR, NB = S::NB;
-  constexpr int MAXM = S::MAXM, WL = S::WL, HITER = S::HITER, HL = S::HL;
-  constexpr bool NT = P >= NT_FROM;
-  constexpr bool UNPAIRED = unpaired_slice_reads(P);
-  __shared__ double sD[ND * ND];
-  __shared__ double skap[NB][K];
-  __shared__ double sx[NB][MAXM];
-  __shared__ double sy[NB][MAXM];
-  __shared__ double sq[NCW * WL];
-  __shared__ double sgr[NCW * WL];
-  __shared__ double sgs[NCW * WL];
-  constexpr int NL = NB + 1; // a list is written when its x loads are issued: up to NB patches before its buffer's turn
-  __shared__ uint32_t sl[NL][MAXM]; // the patches' dof lists (flags in the top bits)
-  __shared__ unsigned ready[NB]; // gathers completed into the buffer, over all its uses
-  __shared__ unsigned done[NB];  // compute waves that have finished with the buffer, over all its uses
-  __shared__ unsigned freed[NB]; // write-backs that have read the buffer's sums out
-
-  const int t = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int lane64 = t & 63;
-  // this workgroup's patches: first + blockIdx.x + i * gridDim.x, i < np
-  const int stride = gridDim.x;
-  const int np = (count - (int)blockIdx.x + stride - 1) / stride;
-  if (t < NB)
-  {
-    ready[t] = 0;
-    done[t] = 0;
-    freed[t] = 0;
-  }
-  if (t < ND * ND)
-    sD[t] = Dg[t];
-  lds_barrier();
-
-  if (wv >= NCW && wv < NCW + NHR)
-  {
-    const int hl = (wv - NCW) * 64 + lane64; // this lane's entries: hl, hl + HL, ...
-    // ================= gather wave: loads only =================
-    // x of the patch's dofs into sx (Dirichlet columns masked), zeros into sy; it never stores to global memory, so
-    // none of its waits queues behind a store's acknowledgement (the vector-memory counter retires in order).
-    // The loads of patch j + 1 are issued as soon as patch j has been handed over; the dof list goes to LDS (sl, one
-    // buffer more than the patch arrays, so that it can be written while both patch buffers are in use).
-    // Software pipeline over the patches: while the cells of patch j are computed, x of patch j + 1 is in flight
-    // (its dof list went to LDS when those loads were issued) and the list of patch j + 2 is on its way.
-    double xv[HITER];
-    uint32_t mk[HITER]; // list of the patch after the one whose x is in flight
-    double kapk = 0.0;
-    int Mx = 0, Ml = 0; // entries of the patch of xv / of mk
-    auto load_list = [&](int j) {
-      const int p = first + (int)blockIdx.x + j * stride;
-      const int off = poff[p];
-      Ml = poff[p + 1] - off;
-#pragma unroll
-      for (int c = 0; c < HITER; ++c)
-      {
-        const int idx = hl + c * HL;
-        mk[c] = pdofs[off + (idx < Ml ? idx : Ml - 1)];
-      }
-    };
-    auto load_x = [&](int j) { // needs mk = list of patch j
-      const int p = first + (int)blockIdx.x + j * stride;
-      uint32_t* slj = sl[j % NL];
-      int cell = 0;
-      if (hl < K)
-        cell = pcell[(size_t)p * K + hl];
-      Mx = Ml;
-#pragma unroll
-      for (int c = 0; c < HITER; ++c)
-        xv[c] = x[mk[c] & PD_MASK];
-      kapk = kappa[cell >= 0 ? cell : 0];
-#pragma unroll
-      for (int c = 0; c < HITER; ++c)
-      {
-        const int idx = hl + c * HL;
-        if (idx < Mx)
-          slj[idx] = mk[c];
-      }
-    };
-    if (np > 0)
-    {
-      load_list(0);
-      load_x(0);
-      if (np > 1)
-        load_list(1);
-    }
-    for (int j = 0; j < np; ++j)
-    {
-      const int b = j % NB, use = j / NB;
-      if (use >= 1 && !pipe_wait(&freed[b], (unsigned)use * NHR, err, 3))
-        return;
-      const uint32_t* slj = sl[j % NL];
-#pragma unroll
-      for (int c = 0; c < HITER; ++c)
-      {
-        const int idx = hl + c * HL;
-        if (idx < Mx)
-        {
-          sx[b][idx] = (slj[idx] & PD_BC) ? 0.0 : xv[c]; // src/laplacian.hpp:186-189
-          sy[b][idx] = 0.0;
-        }
-      }
-      if (hl < K)
-        skap[b][hl] = kapk;
-      pipe_signal(&ready[b]);
-      if (j + 1 < np)
-      {
-        load_x(j + 1);
-        if (j + 2 < np)
-          load_list(j + 2);
-      }
-    }
-    return;
-  }
-  if (wv >= NCW + NHR)
-  {
-    const int hl = (wv - NCW - NHR) * 64 + lane64;
-    // ================= write-back wave: the only one that stores =================
-    // y = (earlier colours' y, where an earlier launch wrote the dof) + the patch's sums.  The old values (and the x
-    // of first-written Dirichlet rows, :273-274) are loaded before the cells of the patch are done.
-    for (int i = 0; i < np; ++i)
-    {
-      const int b = i % NB, use = i / NB;
-      const int p = first + (int)blockIdx.x + i * stride;
-      const int off = poff[p];
-      const int M = poff[p + 1] - off;
-      // the list comes from LDS (the gather wave put it there before it declared the buffer ready)
-      if (!pipe_wait(&ready[b], (unsigned)(use + 1) * NHR, err, 4))
-        return;
-      const uint32_t* sli = sl[i % NL];
-      double yo[HITER];
-#pragma unroll
-      for (int c = 0; c < HITER; ++c)
-      {
-        const int idx = hl + c * HL;
-        const uint32_t mk = sli[idx < M ? idx : M - 1];
-        const uint32_t dof = mk & PD_MASK;
-        const bool acc = !atomic_out && (mk & (PD_ACC | PD_BC)) == PD_ACC;
-        const double* ya = acc ? (const double*)(y + dof) : (x + dof);
-#ifdef PMG_ABL_PIPE_NOWB
-        yo[c] = (double)(size_t)ya;
-#else
-        yo[c] = *ya;
-#endif
-      }
-      if (!pipe_wait(&done[b], (unsigned)(use + 1) * NCW, err, 2))
-        return;
-      constexpr int SB = 8; // entries per lane read, combined and stored at a time
-#pragma unroll
-      for (int c0 = 0; c0 < HITER; c0 += SB)
-      {
-        double v[SB];
-        uint32_t mk[SB];
-#pragma unroll
-        for (int c = c0; c < c0 + SB && c < HITER; ++c)
-        {
-          const int idx = hl + c * HL;
-          v[c - c0] = sy[b][idx < M ? idx : M - 1];
-          mk[c - c0] = sli[idx < M ? idx : M - 1];
-        }
-        if (c0 + SB >= HITER)
-          pipe_signal(&freed[b]); // all sums read (the release fence waits for the reads): the buffer may be refilled
-#pragma unroll
-        for (int c = c0; c < c0 + SB && c < HITER; ++c)
-        {
-          const int idx = hl + c * HL;
-#ifdef PMG_ABL_PIPE_NOWB
-          if (idx < M && v[c - c0] == 1.2345e-300)
-#else
-          if (idx < M)
-#endif
-          {
-            const uint32_t m = mk[c - c0];
-            const uint32_t dof = m & PD_MASK;
-            const bool acc = !atomic_out && (m & (PD_ACC | PD_BC)) == PD_ACC;
-            if (m & PD_BC)
-            {
-              if (!(m & PD_ACC))
-                y[dof] = yo[c]; // = x[dof], :273-274
-            }
-            else if (atomic_out)
-              atomicAdd(&y[dof], v[c - c0]);
-            else
-            {
-              const double r = acc ? yo[c] + v[c - c0] : v[c - c0];
-              if constexpr (NT)
-                __builtin_nontemporal_store(r, &y[dof]);
-              else
-                y[dof] = r;
-            }
-          }
-        }
-      }
-    }
-    return;
-  }
-
-  // ================= compute waves: the cell loop of the column kernel, one item per patch =================
-  const bool lane_ok = lane64 < WL;
-  const int lw = lane_ok ? lane64 : WL - 1;
-  const int cw = lw / NQ2;
-  const int ab = lw - cw * NQ2;
-  const int a = ab / ND, b_ = ab - a * ND;
-  double Da[ND], Db[ND], DTa[ND], DTb[ND]; // D[a][.], D[b][.], D[.][a], D[.][b]
-#pragma unroll
-  for (int mm = 0; mm < ND; ++mm)
-  {
-    Da[mm] = sD[a * ND + mm];
-    Db[mm] = sD[b_ * ND + mm];
-    DTa[mm] = sD[mm * ND + a];
-    DTb[mm] = sD[mm * ND + b_];
-  }
-  double* q_s = sq + wv * WL + cw * NQ2;
-  double* gr_s = sgr + wv * WL + cw * NQ2;
-  double* gs_s = sgs + wv * WL + cw * NQ2;
-  const int slot = wv * CW + cw; // this lane's cell of every patch
-  for (int i = 0; i < np; ++i)
-  {
-    const int bf = i % NB, use = i / NB;
-    const int p = first + (int)blockIdx.x + i * stride;
-    const int table = lmap_id[p];
-    const int nc = pncell[p];
-    const uint16_t* lm = lmaps + (size_t)table * (K * N) + (size_t)slot * N + ab;
-    const double2* Gs = G + ((size_t)p * K + slot) * 3 * N + ab;
-    int l[ND];
-#pragma unroll
-    for (int k = 0; k < ND; ++k)
-      l[k] = lm[k * NQ2];
-    double2 gq[3];
-    gq[0] = gload<NT>(Gs);
-    gq[1] = gload<NT>(Gs + NQ2);
-    gq[2] = gload<NT>(Gs + 2 * NQ2);
-    if (!pipe_wait(&ready[bf], (unsigned)(use + 1) * NHR, err, 1))
-      return;
-#ifdef PMG_ABL_PIPE_NOCOMP
-    if (Dg[0] != 1.2345e-300)
-    {
-      pipe_signal(&done[bf]);
-      continue;
-    }
-#endif
-    const double* sxb = sx[bf];
-    double* syb = sy[bf];
-    const double kap = skap[bf][slot];
-    double u[ND], Aq[ND];
-#pragma unroll
-    for (int k = 0; k < ND; ++k)
-    {
-      u[k] = sxb[l[k]];
-      Aq[k] = 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < ND; ++k)
-    {
-      const double2 g01 = gq[0], g23 = gq[1], g45 = gq[2];
-      if (k + 1 < ND)
-      {
-        gq[0] = gload<NT>(Gs + (k + 1) * 3 * NQ2);
-        gq[1] = gload<NT>(Gs + (k + 1) * 3 * NQ2 + NQ2);
-        gq[2] = gload<NT>(Gs + (k + 1) * 3 * NQ2 + 2 * NQ2);
-      }
-      q_s[ab] = u[k];
-      wave_fence();
-      double qr = 0.0, qs = 0.0, qt = 0.0;
-#pragma unroll
-      for (int mm = 0; mm < ND; ++mm)
-      {
-        qr += Da[mm] * slice_load<UNPAIRED>(q_s[mm * ND + b_]); // d/dx, src/laplacian.hpp:195-199
-        qs += Db[mm] * slice_load<UNPAIRED>(q_s[a * ND + mm]);  // d/dy, :206-210
-        qt += Dg[k * ND + mm] * u[mm];                          // d/dz, :214-218
-      }
-      const double fr = kap * (g01.x * qr + g01.y * qs + g23.x * qt); // :233
-      const double fs = kap * (g01.y * qr + g23.y * qs + g45.x * qt); // :234
-      const double ft = kap * (g23.x * qr + g45.x * qs + g45.y * qt); // :235
-      gr_s[ab] = fr;
-      gs_s[ab] = fs;
-      wave_fence();
-      double acc = 0.0;
-#pragma unroll
-      for (int mm = 0; mm < ND; ++mm)
-      {
-        acc += DTa[mm] * slice_load<UNPAIRED>(gr_s[mm * ND + b_]); // :246-251
-        acc += DTb[mm] * slice_load<UNPAIRED>(gs_s[a * ND + mm]);  // :255-259
-        Aq[mm] += Dg[k * ND + mm] * ft;                            // :263-267
-      }
-      Aq[k] += acc;
-      wave_fence();
-    }
-    const bool contributes = lane_ok && slot < nc;
-#pragma unroll
-    for (int k = 0; k < ND; ++k)
-      atomicAdd(&syb[l[k]], contributes ? Aq[k] : 0.0); // :270,277 -- in LDS (ds_add_f64)
-    pipe_signal(&done[bf]);
-  }
-}
-
 __global__ void zero_list_kernel(int n, const int32_t* __restrict__ idx, double* __restrict__ y)
 {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -1537,21 +1161,6 @@ int launch_stiffness(pmg_laplacian op, const double* x, double* y, int first, in
         stiffness_ring_kernel<P><<<count, RShape<P>::THREADS, 0, s>>>(x, y, G, op->poff, op->pdofs, op->lmap_id, op->lmaps,
                                                                    op->pcell, op->pncell, op->kappa, op->D, first,
                                                                    atomic_out);
-        op->launches++;
-        return PMG_OK;
-      }
-    }
-    if constexpr (pipelined(P))
-    {
-      static_assert(PShape<P>::OK, "patch shape and pipelined kernel do not match");
-      // one persistent workgroup per CU; a launch that cannot give every workgroup two patches to overlap stays
-      // on the column kernel
-      if (op->geometry_mode != 1 && op->batch_patches == 0
-          && (g_pipeline == 2 || (g_pipeline == 1 && count >= 2 * op->num_cus)))
-      {
-        stiffness_pipe_kernel<P><<<std::min(count, op->num_cus), PShape<P>::THREADS, 0, s>>>(
-            x, y, G, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell, op->pncell, op->kappa, op->D, first, count,
-            atomic_out, op->pipe_err);
         op->launches++;
         return PMG_OK;
       }
@@ -1915,13 +1524,6 @@ extern "C" int pmg_laplacian_create_with_tables(
     PMG_HIP(hipMemsetAsync(op->G, 0, sizeof(double2) * (gsize ? gsize : 1), s)); // padding, empty slots
   }
   PMG_HIP(hipMalloc(&op->diag_inv, sizeof(double) * (total ? total : 1)));
-  PMG_HIP(hipMalloc(&op->pipe_err, sizeof(int)));
-  PMG_HIP(hipMemsetAsync(op->pipe_err, 0, sizeof(int), s));
-  {
-    int dev = 0;
-    PMG_HIP(hipGetDevice(&dev));
-    PMG_HIP(hipDeviceGetAttribute(&op->num_cus, hipDeviceAttributeMultiprocessorCount, dev));
-  }
   PMG_HIP(hipEventCreate(&op->ev0));
   PMG_HIP(hipEventCreate(&op->ev1));
   if (nq_total > 0)
@@ -1964,7 +1566,6 @@ extern "C" int pmg_laplacian_destroy(pmg_laplacian op)
   (void)hipFree(op->lmap_id);
   (void)hipFree(op->lmaps);
   (void)hipFree(op->diag_inv);
-  (void)hipFree(op->pipe_err);
   for (hipEvent_t e : op->prof_events)
     (void)hipEventDestroy(e);
   if (op->ev0)
@@ -2148,26 +1749,6 @@ extern "C" int pmg_laplacian_read_profile(pmg_laplacian op, double* total_ms, lo
   *launches = op->prof_launches;
   op->prof_used = 0;
   op->prof_launches = 0;
-  return PMG_OK;
-}
-
-// Status of the kernels' bounded waits: synchronises the stream and returns PMG_ERR_HIP if a wait of the pipelined
-// kernel ever gave up (a hand-off that never arrived -- a library bug, reported instead of a hang).
-extern "C" int pmg_laplacian_check(pmg_laplacian op, pmg_stream stream)
-{
-  PMG_REQUIRE(op, "pmg_laplacian_check: NULL argument");
-  int code = 0;
-  PMG_HIP(hipMemcpyAsync(&code, op->pipe_err, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
-  PMG_HIP(hipStreamSynchronize(S(stream)));
-  if (code != 0)
-    return fail(PMG_ERR_HIP, "stiffness kernel: a bounded wait gave up (code %d)", code);
-  return PMG_OK;
-}
-
-extern "C" int pmg_set_pipelined_apply(int enable)
-{
-  PMG_REQUIRE(enable >= 0 && enable <= 2, "pmg_set_pipelined_apply: 0 (off), 1 (large launches) or 2 (every launch)");
-  pmg::g_pipeline = enable;
   return PMG_OK;
 }
 

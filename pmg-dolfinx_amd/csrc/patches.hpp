@@ -48,7 +48,7 @@ inline constexpr PatchShape patch_shape(int P)
   case 3:
     return {2, 2, 8, 1280};   // M = 7*7*25  = 1225
   case 4:
-    return {2, 2, 6, 2048};   // M = 9*9*25  = 2025: 12 wave items = the compute waves of the pipelined kernel
+    return {2, 2, 8, 2688};   // M = 9*9*33  = 2673
   case 5:
     return {2, 2, 4, 2560};   // M = 11*11*21 = 2541
   case 6:

@@ -41,12 +41,6 @@ def set_merge_threshold(patch_dofs: int):
     call("pmg_set_merge_threshold", int(patch_dofs))
 
 
-def set_pipelined_apply(mode: int):
-    """0: every launch of the degree-4 operator on the one-workgroup-per-patch kernel; 1 (default): launches with
-    at least two patches per CU on the persistent, phase-overlapped kernel; 2: every launch on it.  Process-wide."""
-    call("pmg_set_pipelined_apply", int(mode))
-
-
 class MatFreeLaplacian:
     """y = A x for the GLL-collocated stiffness operator, matrix-free.
 
@@ -124,11 +118,6 @@ class MatFreeLaplacian:
         """"stored" (default, the reference's G[cell][q][6] stream) or "affine"
         (one constant tensor per cell; needs ``is_affine()``)."""
         call("pmg_laplacian_set_geometry_mode", self._handle, {"stored": 0, "affine": 1}[mode])
-
-    def check(self):
-        """Synchronise and raise if a bounded wait inside a kernel of this operator ever gave up
-        (``pmg_laplacian_check``)."""
-        call("pmg_laplacian_check", self._handle, current_stream())
 
     def launches_per_apply(self) -> int:
         return call("pmg_laplacian_launches_per_apply", self._handle)

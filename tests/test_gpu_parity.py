@@ -766,42 +766,3 @@ def test_merged_and_coloured_launches_agree(pm, P, n):
     # no global atomics on the coloured path; inside a patch the cell sums meet in LDS in whatever
     # order the wavefronts arrive, so two runs agree to rounding, not bit for bit
     assert _relerr(got["coloured"][0], got["coloured"][2]) < 1e-14
-
-
-@pytest.mark.parametrize("n", [(3, 2, 9), 7, (16, 16, 15), 24])
-def test_pipelined_kernel_against_oracle(pm, n):
-    """The persistent, phase-overlapped degree-4 kernel (stiffness_pipe_kernel: compute waves + helper waves,
-    double-buffered patches, hand-offs through LDS counters) forced onto every launch -- ragged patches, partial
-    workgroup shares, the coloured and the merged (atomic) write-back, repeated applications into the same
-    output -- against the C oracle and against the one-workgroup-per-patch kernel; no bounded wait may have
-    given up."""
-    from oracle import c_oracle as co
-
-    P = 4
-    part = pm.BoxPartition(n, warp=twist)
-    lv = part.level(P)
-    layout = pm.make_layout(lv)
-    A = co.CLevel(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.bc_marker)
-    rng = np.random.default_rng(11)
-    u = rng.standard_normal(lv.ndofs)
-    ref = A.apply(u)
-    x = _vec(pm, layout, u)
-    got = {}
-    try:
-        for below in (0, 10**12):  # coloured launches / one merged atomic launch
-            pm.set_merge_threshold(below)
-            op = pm.MatFreeLaplacian(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells,
-                                     lv.bc_marker, layout)
-            for mode in (0, 2):
-                pm.set_pipelined_apply(mode)
-                y = pm.Vector(layout)
-                y.set(3.0)
-                for _ in range(3):  # the output of one application is the (overwritten) input state of the next
-                    op(x, y)
-                op.check()
-                got[(below, mode)] = y.data_copy()
-                assert _relerr(got[(below, mode)], ref) < 1e-12, (below, mode)
-            assert _relerr(got[(below, 2)], got[(below, 0)]) < 1e-13
-    finally:
-        pm.set_merge_threshold(-1)
-        pm.set_pipelined_apply(1)

@@ -12,15 +12,12 @@ class V: pass
 big = part.ncells * (P + 1) ** 3 * 2 + 4096  # room for the linear gather / write-back ablations
 x = V(); x.data = torch.randn(big, dtype=torch.float64, device="cuda")
 v = V(); v.data = torch.zeros(big, dtype=torch.float64, device="cuda")
-if "PMG_PIPELINED" in os.environ:
-    pm.set_pipelined_apply(int(os.environ["PMG_PIPELINED"]))
 op.time_kernel(x, v, 3)
 ms = op.time_kernel(x, v, reps) * op.launches_per_apply()
-op.check()
 N, U = (P + 1) ** 3, P ** 3
 alg = (52 * N + 8 + 17 * U) * part.ncells
 if os.environ.get("PMG_GEOMETRY") == "affine":
     op.set_geometry_mode("affine")
     op.time_kernel(x, v, 3)
     ms = op.time_kernel(x, v, reps) * op.launches_per_apply()
-print(f"pipelined={os.environ.get('PMG_PIPELINED','default')} geom={os.environ.get('PMG_GEOMETRY','stored')} lib={os.environ.get('PMG_AMD_LIB','default')} P={P} n={n} kernel {ms*1e3:.1f} us  algorithmic {alg/ms/1e6:.0f} GB/s  ({alg/ms/1e6/8000:.3f} of 8 TB/s)")
+print(f"geom={os.environ.get('PMG_GEOMETRY','stored')} lib={os.environ.get('PMG_AMD_LIB','default')} P={P} n={n} kernel {ms*1e3:.1f} us  algorithmic {alg/ms/1e6:.0f} GB/s  ({alg/ms/1e6/8000:.3f} of 8 TB/s)")
