@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 using namespace pmg;
 
@@ -76,6 +77,7 @@ struct pmg_laplacian_s
   int n_launch_l = 0;
   int n_plain = 0;
   bool needs_zero = false; // some local dof belongs to no listed cell
+  bool stream_policy = true; // the stored tensor exceeds the Infinity Cache: nt loads / stores (launch_stiffness)
   double* diag_inv = nullptr; // [size_local + num_ghosts]
   bool have_diag = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -424,7 +426,7 @@ constexpr bool unpaired_slice_reads(int P) { return P == 5 || P == 8; }
 // P = 4; the register-heavy degrees take what they need (profiles/kernel_resources_r02.md)
 template <int P>
 constexpr int min_waves_per_simd() { return P <= 4 ? (2 * Shape<P>::NW + 3) / 4 : 1; }
-template <int P, bool AFF>
+template <int P, bool AFF, bool NT>
 __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     stiffness_column_kernel(const double* __restrict__ x, double* __restrict__ y,
                             const double2* __restrict__ G, const double* __restrict__ Gaff,
@@ -439,7 +441,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, NQ2 = Sh::NQ2, CW = Sh::CW, NG = Sh::NG, WPC = Sh::WPC;
   constexpr int MAXM = Sh::MAXM, THREADS = Sh::WTHREADS, ITER = Sh::WITER;
   constexpr int WL = CW * NQ2; // columns of one item (a wave, or WPC waves sharing a cell)
-  constexpr bool NT = P >= NT_FROM; // streaming cache policy for G and the y write-back
+  // NT: streaming cache policy for G and the y write-back (chosen per operator, launch_stiffness)
   constexpr bool UNPAIRED = unpaired_slice_reads(P);
   __shared__ double sD[ND * ND];
   __shared__ double skap[K];
@@ -1138,6 +1140,17 @@ int for_each_geometry_chunk(pmg_laplacian op, hipStream_t s, F f)
   return PMG_OK;
 }
 
+// tensor bytes above which the stream is non-temporal.  The Infinity Cache holds 256 MiB, but inside a V-cycle the
+// smoother's vectors pass through it between two applications: measured per cycle, default / nt policy, at 24^3
+// cells (83 MB) 0.417 / 0.445 ms, 32^3 (196 MB) 0.821 / 0.809, 40^3 1.59 / 1.46, 64^3 5.71 / 5.10.
+// PMG_STREAM_POLICY=0 / 1 forces the default / the streaming policy (measurements).
+bool streams_past_the_cache(long long tensor_bytes)
+{
+  if (const char* e = std::getenv("PMG_STREAM_POLICY"))
+    return e[0] != '0';
+  return tensor_bytes > (128LL << 20);
+}
+
 template <int P>
 int launch_stiffness(pmg_laplacian op, const double* x, double* y, int first, int count,
                      int atomic_out, hipStream_t s)
@@ -1165,14 +1178,22 @@ int launch_stiffness(pmg_laplacian op, const double* x, double* y, int first, in
         return PMG_OK;
       }
     }
+    // Cache policy: a tensor that is read once per application and is larger than the Infinity Cache is streamed
+    // (nt), so that it does not displace x, y and the tables; a tensor that fits stays resident between two
+    // applications under the default policy (streams_past_the_cache; profiles/kernel_tuning_r03.md).  The affine mode
+    // reads no tensor.
+    const bool nt = P >= NT_FROM && op->geometry_mode != 1 && op->stream_policy;
+#define PMG_LAUNCH_COLUMN(AFF_, NT_)                                                                                \
+  stiffness_column_kernel<P, AFF_, NT_><<<count, Shape<P>::WTHREADS, 0, s>>>(                                         \
+      x, y, G, op->Gaff, op->W1, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell, op->pncell, op->kappa, op->D,  \
+      first, atomic_out)
     if (op->geometry_mode == 1)
-      stiffness_column_kernel<P, true><<<count, Shape<P>::WTHREADS, 0, s>>>(
-          x, y, G, op->Gaff, op->W1, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell,
-          op->pncell, op->kappa, op->D, first, atomic_out);
+      PMG_LAUNCH_COLUMN(true, (P >= NT_FROM)); // (only the y stores: as before)
+    else if (nt)
+      PMG_LAUNCH_COLUMN(false, true);
     else
-      stiffness_column_kernel<P, false><<<count, Shape<P>::WTHREADS, 0, s>>>(
-          x, y, G, op->Gaff, op->W1, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell,
-          op->pncell, op->kappa, op->D, first, atomic_out);
+      PMG_LAUNCH_COLUMN(false, false);
+#undef PMG_LAUNCH_COLUMN
   }
   op->launches++;
   return PMG_OK;
@@ -1523,6 +1544,7 @@ extern "C" int pmg_laplacian_create_with_tables(
     PMG_HIP(hipMalloc(&op->G, sizeof(double2) * (gsize ? gsize : 1)));
     PMG_HIP(hipMemsetAsync(op->G, 0, sizeof(double2) * (gsize ? gsize : 1), s)); // padding, empty slots
   }
+  op->stream_policy = streams_past_the_cache((long long)sizeof(double2) * gpatch(nd, op->K) * op->npatch);
   PMG_HIP(hipMalloc(&op->diag_inv, sizeof(double) * (total ? total : 1)));
   PMG_HIP(hipEventCreate(&op->ev0));
   PMG_HIP(hipEventCreate(&op->ev1));
@@ -1709,6 +1731,7 @@ extern "C" int pmg_laplacian_set_geometry_batch(pmg_laplacian op, long long batc
   PMG_HIP(hipMalloc(&op->G, sizeof(double2) * (gsize ? gsize : 1)));
   PMG_HIP(hipMemset(op->G, 0, sizeof(double2) * (gsize ? gsize : 1))); // padding of the flat layout
   op->batch_patches = bp;
+  op->stream_policy = streams_past_the_cache((long long)sizeof(double2) * gsize);
   if (bp == 0 && op->npatch > 0) // back to the resident tensor
   {
     batch_geometry(op, 0, op->npatch, nullptr);

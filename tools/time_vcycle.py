@@ -1,12 +1,13 @@
 """Time the config-2 V-cycle (64^3, p = 4 -> 2 -> 1, Chebyshev(3)) alone.
-usage: python tools/time_vcycle.py [reps]"""
+usage: python tools/time_vcycle.py [reps [n]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import pmg_dolfinx_amd as pm
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-H = pm.PoissonHierarchy(64, (1, 2, 4), cheb_its=3)
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+H = pm.PoissonHierarchy(n, (1, 2, 4), cheb_its=3)
 x = H.new_vector()
 x.set(0.0)
 for _ in range(3):
@@ -18,4 +19,4 @@ for _ in range(reps):
 e1.record()
 e1.synchronize()
 ms = e0.elapsed_time(e1) / reps
-print(f"lib={os.environ.get('PMG_AMD_LIB', 'default')} V-cycle {ms:.3f} ms  {H.fine_ndofs_owned / ms / 1e6:.3f} GDoF/s  |x| = {pm.norm(x):.12e}")
+print(f"n={n} policy={os.environ.get('PMG_STREAM_POLICY', 'auto')} lib={os.environ.get('PMG_AMD_LIB', 'default')} V-cycle {ms:.3f} ms  {H.fine_ndofs_owned / ms / 1e6:.3f} GDoF/s  |x| = {pm.norm(x):.12e}")
