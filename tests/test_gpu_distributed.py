@@ -635,3 +635,86 @@ def test_native_exchange_with_several_segments(built):
     (out,) = _run_ranks(_segments_worker, 1, ())
     assert out["fwd"] == 0.0
     assert out["rev"] < 1e-14
+
+
+# ---------------------------------------------------------------------------------------------
+# Real RCCL between GPUs: runs wherever at least two devices are visible (the one-GPU test box skips it).
+# "add one 2-rank test of forward and reverse exchange plus a captured cycle, to run once when a
+# multi-GPU box is available".
+def _multi_gpu_body(rank, world, port, n, dims, orders):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        import pmg_dolfinx_amd as pm
+
+        comm = pm.RcclComm.from_torch(device=torch.device("cuda", rank))
+        assert comm.size() == world
+        out = _rank_checks(pm, rank, world, n, dims, orders, comm=comm)
+        # forward + reverse scatter through the communicator against the partition's own lists
+        H = pm.PoissonHierarchy(n, orders, kappa=2.0, cheb_its=3, proc_dims=dims, rank=rank, size=world, warp=warp,
+                                comm=comm)
+        lv, lay = H.levels[-1], H.layouts[-1]
+        v = pm.Vector(lay)
+        g = np.arange(H.part.global_ndofs(orders[-1]), dtype=np.float64)
+        loc = np.zeros(lv.ndofs)
+        loc[: lv.size_local] = g[lv.local_to_global[: lv.size_local]]
+        v.data.copy_(torch.from_numpy(loc))
+        v.scatter_fwd()
+        out["fwd_ok"] = bool(np.array_equal(v.data_copy(), g[lv.local_to_global]))
+        v.scatter_rev()
+        mult = np.bincount(np.concatenate(dist_all_ghost_globals(dist, lv)), minlength=g.size) + 1.0
+        out["rev_err"] = float(np.abs(v.data_copy()[: lv.size_local]
+                                      - (g * mult)[lv.local_to_global[: lv.size_local]]).max())
+        # eager cycles, then the same cycles replayed as a hipGraph with the exchange captured
+        def cycles(graph):
+            H.mg.set_graph(graph)
+            x = H.new_vector()
+            x.set(0.0)
+            for _ in range(4):
+                H.mg.apply(H.rhs[-1], x)
+            torch.cuda.synchronize()
+            return x.data_copy()[: lv.size_local].copy(), H.mg.graph_replays()
+
+        xe, r0 = cycles(False)
+        xg, r1 = cycles(True)
+        H.mg.set_graph(False)
+        out["graph_replays"] = r1 - r0
+        out["graph_vs_eager"] = float(np.abs(xg - xe).max() / np.abs(xe).max())
+        return out
+    finally:
+        dist.destroy_process_group()
+
+
+def dist_all_ghost_globals(dist, lv):
+    """Global indices of every rank's ghosts (how often each owned dof is ghosted elsewhere)."""
+    mine = np.asarray(lv.local_to_global[lv.size_local:], dtype=np.int64)
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, mine)
+    return gathered
+
+
+def _multi_gpu_worker(rank, world, port, n, dims, orders, q):
+    _reporting(_multi_gpu_body)(rank, world, port, n, dims, orders, q)
+
+
+@pytest.mark.parametrize("dims,n", [((1, 1, 1), (4, 4, 4)), ((1, 1, 2), (4, 4, 8)), ((2, 2, 2), (6, 6, 6))])
+def test_native_rccl_between_gpus(dims, n, built):
+    """(1, 1, 1) is the rehearsal of this test's own code on a one-GPU box: a torch nccl group and a library
+    communicator of one rank, no halo."""
+    import torch
+
+    world = dims[0] * dims[1] * dims[2]
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, {torch.cuda.device_count()} visible")
+    res = _run_ranks(_multi_gpu_worker, world, (n, dims, (1, 2, 4)), timeout=600)
+    if world > 1:
+        _assert_rank_results(res)
+    for out in res:
+        assert out["fwd_ok"] and out["rev_err"] == 0.0
+        assert out["graph_replays"] >= 3 and out["graph_vs_eager"] < 1e-12
