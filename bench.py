@@ -297,7 +297,7 @@ def main():
     alg_bytes = algorithmic_bytes_per_cell(P) * ncells_launch
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    for tname in ("hbm_traffic_r02.json", "hbm_traffic_r01.json"):
+    for tname in ("hbm_traffic_r03.json", "hbm_traffic_r02.json", "hbm_traffic_r01.json"):
         tfile = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tfile):
             try:

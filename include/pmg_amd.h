@@ -371,6 +371,13 @@ int pmg_amg_destroy(pmg_amg amg);
 int pmg_amg_set_smoother_iterations(pmg_amg amg, int k); /* Chebyshev degree per pre/post smooth (2) */
 int pmg_amg_set_cycles(pmg_amg amg, int cycles);
 int pmg_amg_set_krylov(pmg_amg amg, int max_iter, double rtol);
+/* Replicated form only.  1 (the default when the hierarchy has more than one level): level 0 of the hierarchy -- the
+ * degree-1 level itself, three quarters of a cycle's work -- is smoothed on the PARTITIONED operator (matrix-free
+ * application with its halo exchange), each rank restricts its owned residual, ONE all-reduce of a level-1 vector
+ * (about 1/9 of the level-0 size) forms the replicated right-hand side of level 1, and only the levels from 1 down are
+ * solved redundantly on every rank.  0: the whole hierarchy replicated, one all-reduce of a level-0 vector per solve
+ * (the redundant work then grows with the rank count).  Same arithmetic up to summation order either way. */
+int pmg_amg_set_distributed_fine_level(pmg_amg amg, int enable);
 /* solve(x, b) of src/amg.hpp:67-68; *iterations = CG iterations (or cycles) used. */
 int pmg_amg_solve(pmg_amg amg, double* x, const double* b, int* iterations, pmg_stream stream);
 /* One V-cycle of the hierarchy from a zero initial guess: x = M b (the preconditioner alone). */

@@ -125,6 +125,7 @@ _SIGS = {
     "pmg_amg_set_smoother_iterations": (C.c_int, [vp, C.c_int]),
     "pmg_amg_set_cycles": (C.c_int, [vp, C.c_int]),
     "pmg_amg_set_krylov": (C.c_int, [vp, C.c_int, C.c_double]),
+    "pmg_amg_set_distributed_fine_level": (C.c_int, [vp, C.c_int]),
     "pmg_amg_solve": (C.c_int, [vp, vp, vp, C.POINTER(C.c_int), vp]),
     "pmg_amg_cycle": (C.c_int, [vp, vp, vp, vp]),
     "pmg_amg_num_levels": (C.c_int, [vp]),

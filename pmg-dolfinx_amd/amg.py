@@ -21,9 +21,11 @@ class AmgSolver:
     operator with no host synchronisation (single rank)."""
 
     def __init__(self, op, max_iter: int = 60, rtol: float = 1e-5, cycles: int = 0, smoother_iterations: int = 2,
-                 global_index=None, n_global=None):
+                 global_index=None, n_global=None, distributed_fine_level=None):
         """``global_index`` (local -> global dof numbers, owned then ghosts) and ``n_global``: the replicated
-        form for several ranks -- the global coarse matrix gathered on every rank, one all-reduce per solve."""
+        form for several ranks -- the hierarchy built on the gathered global matrix on every rank; by default only
+        the levels below the first stay replicated in the solve (``distributed_fine_level``, see
+        ``pmg_amg_set_distributed_fine_level``)."""
         self.op = op  # must outlive the handle
         h = vp()
         if global_index is not None:
@@ -35,6 +37,8 @@ class AmgSolver:
         else:
             call("pmg_amg_create", C.byref(h), op.handle, current_stream())
         self._handle = h
+        if distributed_fine_level is not None:  # replicated form: level 0 on the partitioned operator (default) or not
+            call("pmg_amg_set_distributed_fine_level", h, 1 if distributed_fine_level else 0)
         call("pmg_amg_set_smoother_iterations", h, int(smoother_iterations))
         if cycles > 0:
             call("pmg_amg_set_cycles", h, int(cycles))

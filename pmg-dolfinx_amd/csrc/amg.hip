@@ -47,6 +47,7 @@ using namespace pmg;
 namespace pmg
 {
 int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s);
+const double* laplacian_diag_inv(pmg_laplacian op);
 pmg_layout laplacian_layout(pmg_laplacian op);
 PatchView laplacian_patches(pmg_laplacian op);
 struct LaplacianInputs
@@ -500,6 +501,14 @@ struct pmg_amg_s
   double *gb = nullptr, *gx = nullptr; // [n_global] device
   double* h_stage = nullptr;    // pinned, [n_global]: the callback route of the all-reduce
   pmg_layout glayout = nullptr; // the replicated problem seen as one rank's (Krylov work vectors)
+  // Distributed fine level (replicated form, default): level 0 -- three quarters of a cycle's work -- stays on the
+  // partitioned degree-1 operator (matrix-free application with its halo exchange, the layout's own smoother data);
+  // only the levels below it are replicated.  A cycle then moves ONE all-reduce of a level-1 vector (1/9 of the
+  // level-0 size) instead of a level-0 one, and every rank smooths its own share of level 0 instead of all of it.
+  bool dist0 = false;
+  DevCsr P0l, R0l; // the level 0 -> 1 transfer restricted to the owned dofs: [size_local x n1], [n1 x size_local]
+  double *d0_r = nullptr, *d0_z = nullptr, *d0_q = nullptr, *d0_b = nullptr, *d0_xc = nullptr; // on the layout
+  pmg_cg cg0 = nullptr; // Krylov mode on the layout (distributed dot products)
   // host copy of the hierarchy for pmg_amg_export (tests)
   std::vector<HostCsr> hA, hP;
   std::vector<double> hlmax;
@@ -609,7 +618,7 @@ long long amg_capture_state(pmg_amg amg)
 {
   if (amg->cycles <= 0 || (amg->replicated && !amg->layout->comm && amg->layout->allreduce))
     return -1;
-  return ((long long)amg->cycles << 16) ^ amg->smoother_its ^ (amg->replicated ? 1 << 30 : 0);
+  return ((long long)amg->cycles << 16) ^ amg->smoother_its ^ (amg->replicated ? 1 << 30 : 0) ^ (amg->dist0 ? 1 << 29 : 0);
 }
 } // namespace pmg
 
@@ -640,6 +649,73 @@ int solve_on(pmg_amg amg, double* x, const double* b, int n, size_t total, const
 }
 } // namespace
 
+namespace
+{
+// sum a device vector over the ranks of the layout (communicator, or the callbacks through pinned memory)
+int device_allreduce_sum(pmg_amg amg, double* v, int n, hipStream_t s)
+{
+  pmg_layout l = amg->layout;
+  if (l->comm)
+    return comm_allreduce(l, v, n, false, s);
+  if (l->allreduce)
+  {
+    PMG_HIP(hipMemcpyAsync(amg->h_stage, v, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    PMG_HIP(hipStreamSynchronize(s));
+    for (size_t o = 0; o < (size_t)n; o += (size_t)1 << 24)
+      if (l->allreduce(l->user, amg->h_stage + o, (int)std::min<size_t>((size_t)1 << 24, n - o)) != 0)
+        return fail(PMG_ERR_INVALID, "allreduce callback failed");
+    PMG_HIP(hipMemcpyAsync(v, amg->h_stage, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  }
+  return PMG_OK;
+}
+
+// One V(k, k) cycle with the fine level distributed: x = cycle(b) on the layout's vectors, zero initial guess.
+int dist_cycle(pmg_amg amg, double* x, const double* b, hipStream_t s)
+{
+  pmg_layout l = amg->layout;
+  pmg_laplacian op = amg->op;
+  const int n = l->size_local;
+  AmgLevel& l0 = amg->levels[0];
+  AmgLevel& l1 = amg->levels[1];
+  const ChebWork w{amg->d0_r, amg->d0_z, amg->d0_q};
+  const ApplyFn A = [op, s](double* in, double* out) { return laplacian_apply(op, in, out, s); };
+  const double* dinv = laplacian_diag_inv(op);
+  PMG_TRY(cheb_iterate(w, A, dinv, n, l0.lmax, amg->smoother_its, x, b, ResidualUpdated, true, s)); // r = b - A x
+  PMG_TRY(csr_product<0>(amg->R0l, amg->d0_r, nullptr, l1.b, s)); // this rank's share of R r
+  PMG_TRY(device_allreduce_sum(amg, l1.b, l1.n, s));
+  PMG_TRY(amg_cycle(amg, 1, l1.x, l1.b, s));                      // replicated from here down
+  PMG_TRY(csr_product<2>(amg->P0l, l1.x, nullptr, x, s));         // x += P x_c, owned rows
+  PMG_TRY(cheb_iterate(w, A, dinv, n, l0.lmax, amg->smoother_its, x, b, ResidualNone, false, s));
+  return PMG_OK;
+}
+
+int dist_solve(pmg_amg amg, double* x, const double* b, hipStream_t s)
+{
+  pmg_layout l = amg->layout;
+  pmg_laplacian op = amg->op;
+  const int n = l->size_local;
+  if (amg->cycles > 0)
+  {
+    PMG_TRY(dist_cycle(amg, x, b, s));
+    for (int c = 1; c < amg->cycles; ++c) // x += cycle(b - A x)
+    {
+      PMG_TRY(laplacian_apply(op, x, amg->d0_q, s));
+      launch_axpy(n, amg->d0_b, -1.0, amg->d0_q, b, s);
+      PMG_TRY(dist_cycle(amg, amg->d0_xc, amg->d0_b, s));
+      launch_add(n, x, amg->d0_xc, s);
+    }
+    amg->last_iterations = amg->cycles;
+    return PMG_OK;
+  }
+  PMG_HIP(hipMemsetAsync(x, 0, sizeof(double) * l->total(), s)); // KSP-style zero initial guess
+  const ApplyFn A = [op, s](double* in, double* out) { return laplacian_apply(op, in, out, s); };
+  const PrecondFn M = [amg, s](double* z, const double* r) { return dist_cycle(amg, z, r, s); };
+  PMG_TRY(pmg_cg_set_max_iterations(amg->cg0, amg->max_iter));
+  PMG_TRY(pmg_cg_set_tolerance(amg->cg0, amg->rtol));
+  return cg_iterate(amg->cg0, A, nullptr, &M, false, x, b, &amg->last_iterations, s);
+}
+} // namespace
+
 namespace pmg
 {
 // x = (approximately) A^-1 b on the coarsest p-level, x zero on entry is not assumed
@@ -648,6 +724,8 @@ int amg_solve(pmg_amg amg, double* x, const double* b, hipStream_t s)
   Range range("pmg:amg_solve");
   pmg_layout l = amg->layout;
   const int n = l->size_local;
+  if (amg->replicated && amg->dist0)
+    return dist_solve(amg, x, b, s);
   if (amg->replicated)
   {
     // gather the right-hand side (zero-padded global vector, summed over the ranks), solve the WHOLE
@@ -908,6 +986,34 @@ static int amg_create(pmg_amg* out, pmg_laplacian op, const int64_t* global_inde
   }
   PMG_TRY(build_hierarchy(amg, std::move(A0), level0_len));
   PMG_TRY(pmg_cg_create(&amg->cg, replicated ? amg->glayout : layout));
+  if (replicated && amg->levels.size() >= 2)
+  {
+    // the rows of P_0 of this rank's owned dofs, in the layout's numbering; R_0 restricted likewise
+    const HostCsr& P0 = amg->hP[0];
+    HostCsr Pl;
+    Pl.n = n;
+    Pl.m = P0.m;
+    Pl.rp.assign(n + 1, 0);
+    for (int i = 0; i < n; ++i)
+    {
+      const int g = (int)global_index[i];
+      for (int e = P0.rp[g]; e < P0.rp[g + 1]; ++e)
+      {
+        Pl.ci.push_back(P0.ci[e]);
+        Pl.v.push_back(P0.v[e]);
+      }
+      Pl.rp[i + 1] = (int)Pl.ci.size();
+    }
+    PMG_TRY(upload_csr(amg->P0l, Pl));
+    PMG_TRY(upload_csr(amg->R0l, transpose(Pl)));
+    PMG_TRY(alloc_d(&amg->d0_r, total));
+    PMG_TRY(alloc_d(&amg->d0_z, total));
+    PMG_TRY(alloc_d(&amg->d0_q, total));
+    PMG_TRY(alloc_d(&amg->d0_b, total));
+    PMG_TRY(alloc_d(&amg->d0_xc, total));
+    PMG_TRY(pmg_cg_create(&amg->cg0, layout));
+    amg->dist0 = true;
+  }
   PMG_HIP(hipStreamSynchronize(s));
   *out = guard.release();
   return PMG_OK;
@@ -1025,6 +1131,14 @@ extern "C" int pmg_amg_destroy(pmg_amg amg)
   (void)hipFree(amg->gx);
   if (amg->h_stage)
     (void)hipHostFree(amg->h_stage);
+  free_csr(amg->P0l);
+  free_csr(amg->R0l);
+  (void)hipFree(amg->d0_r);
+  (void)hipFree(amg->d0_z);
+  (void)hipFree(amg->d0_q);
+  (void)hipFree(amg->d0_b);
+  (void)hipFree(amg->d0_xc);
+  pmg_cg_destroy(amg->cg0);
   pmg_cg_destroy(amg->cg);
   pmg_layout_destroy(amg->glayout);
   delete amg;
@@ -1042,6 +1156,17 @@ extern "C" int pmg_amg_set_cycles(pmg_amg amg, int cycles)
 {
   PMG_REQUIRE(amg && cycles >= 0, "pmg_amg_set_cycles: bad argument");
   amg->cycles = cycles;
+  return PMG_OK;
+}
+
+// Replicated form: 1 (default where the hierarchy has a second level) = level 0 stays on the partitioned operator,
+// only the levels below are replicated; 0 = the whole hierarchy replicated (round 2's form).
+extern "C" int pmg_amg_set_distributed_fine_level(pmg_amg amg, int enable)
+{
+  PMG_REQUIRE(amg, "pmg_amg_set_distributed_fine_level: NULL argument");
+  PMG_REQUIRE(amg->replicated, "pmg_amg_set_distributed_fine_level: not a replicated hierarchy");
+  PMG_REQUIRE(!enable || amg->cg0, "pmg_amg_set_distributed_fine_level: the hierarchy has one level only");
+  amg->dist0 = enable != 0;
   return PMG_OK;
 }
 

@@ -172,6 +172,14 @@ def _rank_checks(pm, rank, world, n, dims, orders, comm=None):
     out["rep_err"] = float(np.abs(xl.data_copy()[: lv0.size_local] - xs[lv0.local_to_global[: lv0.size_local]]).max()
                            / np.abs(xs).max())
     out["rep_levels"] = rep.info()
+    # the same hierarchy with level 0 replicated as well (round 2's form): same solution, same iteration count +- 1
+    rep_full = pm.AmgSolver(H.operators[0], max_iter=60, rtol=1e-9, global_index=lv0.local_to_global,
+                            n_global=H.part.global_ndofs(orders[0]), distributed_fine_level=False)
+    xf = pm.Vector(H.layouts[0])
+    out["rep_full_its"] = rep_full.solve(xf, bl)
+    out["rep_dist_vs_full"] = float(np.abs(xf.data_copy()[: lv0.size_local] - xl.data_copy()[: lv0.size_local]).max()
+                                    / np.abs(xs).max())
+    del rep_full, xf
     reps = pm.AmgSolver(H.operators[0], cycles=8, global_index=lv0.local_to_global,
                         n_global=H.part.global_ndofs(orders[0]))
     H.mg.set_coarse_solver(reps)
@@ -201,6 +209,9 @@ def _assert_rank_results(res):
     # the replicated hierarchy is the same on every rank, and it is the single-rank hierarchy
     assert all(out["rep_its"] == res[0]["rep_its"] and out["rep_levels"] == res[0]["rep_levels"] for out in res)
     assert res[0]["rep_its"] <= 14
+    for out in res:
+        assert abs(out["rep_full_its"] - out["rep_its"]) <= 1 and out["rep_dist_vs_full"] < 1e-7, (
+            out["rep_full_its"], out["rep_its"], out["rep_dist_vs_full"])
 
 
 def _worker_body(rank, world, port, n, dims, orders):

@@ -57,7 +57,7 @@ for k in sorted(fetch):
     if k.strip().startswith("ew_kernel2<Cheb") and "<true" in k:
         out.setdefault("vector_kernels_bytes_per_launch", {})[k.strip()] = {
             "fetch_kb_raw": fk, "write_kb": wk, "hbm_bytes_corrected": (2 * fk + wk) * 1024}
-    if "stiffness_column_kernel<4, false>" in k:
+    if "stiffness_column_kernel<4, false" in k:  # <P, stored geometry[, streaming policy]>
         raw = (fk + wk) * 1024
         corrected = raw + g_bytes / 2
         out["stiffness_p4_fetch_kb_raw"] = fk
