@@ -231,7 +231,8 @@ int pmg_laplacian_set_geometry_mode(pmg_laplacian op, int mode);
  * with batch_cells > 0 the tensor G is not kept; every application recomputes it for about
  * batch_cells cells at a time (rounded up to whole patches) into a buffer of that size, right
  * before the cells' stiffness launch -- the reference's memory / time trade, bit-identical
- * results.  0 (default) keeps G resident (288 GB of HBM).  pmg_laplacian_geometry_bytes
+ * results.  0 (default) keeps G resident: 48 bytes per quadrature point, 1.57 GB for 64^3 cells of degree 4 (the
+ * card has 288 GB).  pmg_laplacian_geometry_bytes
  * returns the size of the tensor buffer currently held. */
 int pmg_laplacian_set_geometry_batch(pmg_laplacian op, long long batch_cells);
 long long pmg_laplacian_geometry_bytes(pmg_laplacian op);
