@@ -320,7 +320,9 @@ class _ThreadComm:
         host[:] = tot
 
 
-def test_eight_ranks_2x2x2_as_threads(built):
+@pytest.mark.parametrize("n,orders", [((8, 8, 8), (1, 2, 4)),   # BASELINE config 3's levels, 4 x 4 x 4 cells per brick
+                                      ((6, 6, 6), (1, 3, 6))])  # BASELINE config 5's: p = 6 -> 3 -> 1 + AMG at p = 1
+def test_eight_ranks_2x2x2_as_threads(built, n, orders):
     import threading
 
     import torch
@@ -329,7 +331,7 @@ def test_eight_ranks_2x2x2_as_threads(built):
         pytest.skip("no GPU")
     import pmg_dolfinx_amd as pm
 
-    dims, n, orders = (2, 2, 2), (8, 8, 8), (1, 2, 4)  # 4 x 4 x 4 cells per brick
+    dims = (2, 2, 2)
     world = 8
     W = _ThreadWorld(world)
     res, errors = [None] * world, []
