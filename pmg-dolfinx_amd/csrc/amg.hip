@@ -38,9 +38,15 @@
 #include "patches.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <cmath>
 #include <numeric>
 #include <random>
+#include <thread>
 
 using namespace pmg;
 
@@ -63,6 +69,20 @@ LaplacianInputs laplacian_inputs(pmg_laplacian op);
 
 namespace
 {
+struct StageTimer
+{
+  bool on = std::getenv("PMG_AMG_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void lap(const char* what)
+  {
+    if (!on)
+      return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[pmg_amg set-up] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 struct HostCsr
 {
   int n = 0, m = 0; // rows, columns
@@ -183,6 +203,70 @@ __global__ void dense_apply_kernel(int n, const double* __restrict__ Ainv, const
     y[row] = acc;
 }
 
+// ---- host threads for the set-up ------------------------------------------------------------
+// The set-up runs on the host.  Its row-wise loops are cut into fixed blocks of rows that a few threads pull from a
+// counter; every block's result depends on the block alone and partial sums are combined in block order, so the
+// hierarchy is bit-identical whatever the number of threads -- which the replicated form relies on: every rank must
+// build the same hierarchy.
+int host_threads()
+{
+  static int cached = 0;
+  if (cached == 0)
+  {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1)
+      n = 1;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) // the container's CPU quota, not the host's core count
+    {
+      char q[32] = {0};
+      long long per = 0;
+      if (std::fscanf(f, "%31s %lld", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0)
+        n = std::min<long long>(n, std::max<long long>(1, (std::atoll(q) + per / 2) / per));
+      std::fclose(f);
+    }
+    n = std::min(n, 16);
+    if (const char* e = std::getenv("PMG_HOST_THREADS"))
+      n = std::max(1, std::atoi(e));
+    cached = n;
+  }
+  return cached;
+}
+constexpr int ROW_BLOCK = 4096;
+// f(block, first row, last row (exclusive), thread) for every block of [0, n)
+template <typename F>
+void for_row_blocks(int n, F f)
+{
+  const int nb = (n + ROW_BLOCK - 1) / ROW_BLOCK;
+  const int T = std::min(host_threads(), std::max(nb, 1));
+  if (T <= 1)
+  {
+    for (int b = 0; b < nb; ++b)
+      f(b, b * ROW_BLOCK, std::min(n, (b + 1) * ROW_BLOCK), 0);
+    return;
+  }
+  std::atomic<int> next(0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t] {
+      for (int b = next.fetch_add(1); b < nb; b = next.fetch_add(1))
+        f(b, b * ROW_BLOCK, std::min(n, (b + 1) * ROW_BLOCK), t);
+    });
+  for (auto& x : th)
+    x.join();
+}
+// rows produced block by block -> one CSR matrix (row lengths in C.rp[i + 1] on entry)
+void assemble_blocks(HostCsr& C, const std::vector<std::vector<int>>& bci, const std::vector<std::vector<double>>& bv)
+{
+  for (int i = 0; i < C.n; ++i)
+    C.rp[i + 1] += C.rp[i];
+  C.ci.resize(C.rp[C.n]);
+  C.v.resize(C.rp[C.n]);
+  for_row_blocks(C.n, [&](int b, int r0, int, int) {
+    std::copy(bci[b].begin(), bci[b].end(), C.ci.begin() + C.rp[r0]);
+    std::copy(bv[b].begin(), bv[b].end(), C.v.begin() + C.rp[r0]);
+  });
+}
+
 // ---- host sparse algebra -------------------------------------------------------------------
 HostCsr transpose(const HostCsr& A)
 {
@@ -214,35 +298,47 @@ HostCsr spgemm(const HostCsr& A, const HostCsr& B)
   C.n = A.n;
   C.m = B.m;
   C.rp.assign(C.n + 1, 0);
-  std::vector<int> marker(B.m, -1), cols;
-  std::vector<double> acc(B.m, 0.0);
-  for (int i = 0; i < A.n; ++i)
-  {
-    cols.clear();
-    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
+  const int nb = (A.n + ROW_BLOCK - 1) / ROW_BLOCK, T = host_threads();
+  std::vector<std::vector<int>> bci(nb), marker(T);
+  std::vector<std::vector<double>> bv(nb), acc(T);
+  for_row_blocks(A.n, [&](int blk, int r0, int r1, int t) {
+    if (marker[t].empty())
     {
-      const int j = A.ci[k];
-      const double a = A.v[k];
-      for (int l = B.rp[j]; l < B.rp[j + 1]; ++l)
+      marker[t].assign(B.m, -1);
+      acc[t].assign(B.m, 0.0);
+    }
+    std::vector<int>& mk = marker[t];
+    std::vector<double>& ac = acc[t];
+    std::vector<int> cols;
+    for (int i = r0; i < r1; ++i)
+    {
+      cols.clear();
+      for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
       {
-        const int c = B.ci[l];
-        if (marker[c] != i)
+        const int j = A.ci[k];
+        const double a = A.v[k];
+        for (int l = B.rp[j]; l < B.rp[j + 1]; ++l)
         {
-          marker[c] = i;
-          acc[c] = 0.0;
-          cols.push_back(c);
+          const int c = B.ci[l];
+          if (mk[c] != i)
+          {
+            mk[c] = i;
+            ac[c] = 0.0;
+            cols.push_back(c);
+          }
+          ac[c] += a * B.v[l];
         }
-        acc[c] += a * B.v[l];
       }
+      std::sort(cols.begin(), cols.end());
+      for (int c : cols)
+      {
+        bci[blk].push_back(c);
+        bv[blk].push_back(ac[c]);
+      }
+      C.rp[i + 1] = (int)cols.size();
     }
-    std::sort(cols.begin(), cols.end());
-    for (int c : cols)
-    {
-      C.ci.push_back(c);
-      C.v.push_back(acc[c]);
-    }
-    C.rp[i + 1] = (int)C.ci.size();
-  }
+  });
+  assemble_blocks(C, bci, bv);
   return C;
 }
 
@@ -269,26 +365,38 @@ double lambda_max_jacobi(const HostCsr& A, const std::vector<double>& d, int its
   for (double& v : x)
     v = U(gen);
   double lam = 1.0;
+  const int nb = (n + ROW_BLOCK - 1) / ROW_BLOCK;
+  std::vector<double> py(nb), px(nb);
   for (int it = 0; it < its; ++it)
   {
-    double nrm = 0;
-    for (int i = 0; i < n; ++i)
+    for_row_blocks(n, [&](int blk, int r0, int r1, int) {
+      double sy = 0, sx = 0;
+      for (int i = r0; i < r1; ++i)
+      {
+        double s = 0;
+        for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
+          s += A.v[k] * x[A.ci[k]];
+        y[i] = s / d[i];
+        sy += y[i] * y[i];
+        sx += x[i] * x[i];
+      }
+      py[blk] = sy;
+      px[blk] = sx;
+    });
+    double nrm = 0, xn = 0;
+    for (int blk = 0; blk < nb; ++blk) // block order: the same sums whatever the number of threads
     {
-      double s = 0;
-      for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
-        s += A.v[k] * x[A.ci[k]];
-      y[i] = s / d[i];
-      nrm += y[i] * y[i];
+      nrm += py[blk];
+      xn += px[blk];
     }
     nrm = std::sqrt(nrm);
     if (!(nrm > 0))
       return 1.0;
-    double xn = 0;
-    for (int i = 0; i < n; ++i)
-      xn += x[i] * x[i];
     lam = nrm / std::sqrt(xn);
-    for (int i = 0; i < n; ++i)
-      x[i] = y[i] / nrm;
+    for_row_blocks(n, [&](int, int r0, int r1, int) {
+      for (int i = r0; i < r1; ++i)
+        x[i] = y[i] / nrm;
+    });
   }
   return lam;
 }
@@ -381,39 +489,53 @@ HostCsr smoothed_prolongator(const HostCsr& A, const std::vector<double>& d, con
   P.n = n;
   P.m = na;
   P.rp.assign(n + 1, 0);
-  std::vector<int> marker(na, -1), cols;
-  std::vector<double> acc(na, 0.0);
-  for (int i = 0; i < n; ++i)
-  {
-    cols.clear();
-    auto add = [&](int c, double val) {
-      if (marker[c] != i)
-      {
-        marker[c] = i;
-        acc[c] = 0.0;
-        cols.push_back(c);
-      }
-      acc[c] += val;
-    };
-    if (agg[i] >= 0)
+  const int nb = (n + ROW_BLOCK - 1) / ROW_BLOCK, T = host_threads();
+  std::vector<std::vector<int>> bci(nb), markers(T);
+  std::vector<std::vector<double>> bv(nb), accs(T);
+  for_row_blocks(n, [&](int blk, int r0, int r1, int th) {
+    if (markers[th].empty())
     {
-      add(agg[i], t[i]);
-      for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
-      {
-        const int j = A.ci[k];
-        if (agg[j] >= 0)
-          add(agg[j], -omega * A.v[k] / d[i] * t[j]);
-      }
+      markers[th].assign(std::max(na, 1), -1);
+      accs[th].assign(std::max(na, 1), 0.0);
     }
-    std::sort(cols.begin(), cols.end());
-    for (int c : cols)
-      if (acc[c] != 0.0)
+    std::vector<int>& marker = markers[th];
+    std::vector<double>& acc = accs[th];
+    std::vector<int> cols;
+    for (int i = r0; i < r1; ++i)
+    {
+      cols.clear();
+      auto add = [&](int c, double val) {
+        if (marker[c] != i)
+        {
+          marker[c] = i;
+          acc[c] = 0.0;
+          cols.push_back(c);
+        }
+        acc[c] += val;
+      };
+      if (agg[i] >= 0)
       {
-        P.ci.push_back(c);
-        P.v.push_back(acc[c]);
+        add(agg[i], t[i]);
+        for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
+        {
+          const int j = A.ci[k];
+          if (agg[j] >= 0)
+            add(agg[j], -omega * A.v[k] / d[i] * t[j]);
+        }
       }
-    P.rp[i + 1] = (int)P.ci.size();
-  }
+      std::sort(cols.begin(), cols.end());
+      int len = 0;
+      for (int c : cols)
+        if (acc[c] != 0.0)
+        {
+          bci[blk].push_back(c);
+          bv[blk].push_back(acc[c]);
+          ++len;
+        }
+      P.rp[i + 1] = len;
+    }
+  });
+  assemble_blocks(P, bci, bv);
   return P;
 }
 
@@ -790,6 +912,7 @@ static int amg_create(pmg_amg* out, pmg_laplacian op, const int64_t* global_inde
   amg->replicated = replicated;
   amg->n_global = replicated ? (int32_t)n_global : 0;
 
+  StageTimer tmc;
   // ---- level 0: assemble the owned block of the degree-1 stiffness matrix ----
   std::vector<int32_t> dofmap((size_t)in.ncells * 8);
   std::vector<int8_t> bc(total);
@@ -922,6 +1045,7 @@ static int amg_create(pmg_amg* out, pmg_laplacian op, const int64_t* global_inde
     }
   }
 
+  tmc.lap("level-0 assembly");
   size_t level0_len = (size_t)total;
   if (replicated)
   {
@@ -956,21 +1080,32 @@ static int amg_create(pmg_amg* out, pmg_laplacian op, const int64_t* global_inde
     HostCsr Ag;
     Ag.n = Ag.m = (int)ng;
     Ag.rp.assign(ng + 1, 0);
-    std::vector<std::pair<int, double>> row;
-    for (size_t g = 0; g < ng; ++g)
     {
-      row.clear();
-      for (int k = 0; k < W; ++k)
-        if (gc[g * W + k] > 0.5)
-          row.emplace_back((int)(gc[g * W + k] - 0.5), gv[g * W + k]);
-      PMG_REQUIRE(!row.empty(), "pmg_amg_create_replicated: global dof %zu is owned by no rank", g);
-      std::sort(row.begin(), row.end());
-      for (auto& e : row)
-      {
-        Ag.ci.push_back(e.first);
-        Ag.v.push_back(e.second);
-      }
-      Ag.rp[g + 1] = (int)Ag.ci.size();
+      const int nbk = ((int)ng + ROW_BLOCK - 1) / ROW_BLOCK;
+      std::vector<std::vector<int>> bci(nbk);
+      std::vector<std::vector<double>> bv(nbk);
+      std::atomic<long long> unowned(-1);
+      for_row_blocks((int)ng, [&](int blk, int r0, int r1, int) {
+        std::vector<std::pair<int, double>> row;
+        for (int g = r0; g < r1; ++g)
+        {
+          row.clear();
+          for (int k = 0; k < W; ++k)
+            if (gc[(size_t)g * W + k] > 0.5)
+              row.emplace_back((int)(gc[(size_t)g * W + k] - 0.5), gv[(size_t)g * W + k]);
+          if (row.empty())
+            unowned.store(g);
+          std::sort(row.begin(), row.end());
+          for (auto& e : row)
+          {
+            bci[blk].push_back(e.first);
+            bv[blk].push_back(e.second);
+          }
+          Ag.rp[g + 1] = (int)row.size();
+        }
+      });
+      PMG_REQUIRE(unowned.load() < 0, "pmg_amg_create_replicated: global dof %lld is owned by no rank", unowned.load());
+      assemble_blocks(Ag, bci, bv);
     }
     A0 = std::move(Ag);
     level0_len = ng;
@@ -984,6 +1119,7 @@ static int amg_create(pmg_amg* out, pmg_laplacian op, const int64_t* global_inde
     PMG_TRY(pmg_layout_create(&amg->glayout, (int32_t)ng, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
                               nullptr, nullptr));
   }
+  tmc.lap("gather (replicated form)");
   PMG_TRY(build_hierarchy(amg, std::move(A0), level0_len));
   PMG_TRY(pmg_cg_create(&amg->cg, replicated ? amg->glayout : layout));
   if (replicated && amg->levels.size() >= 2)
@@ -1035,6 +1171,7 @@ namespace
 {
 int build_hierarchy(pmg_amg amg, HostCsr&& A0, size_t level0_len)
 {
+  StageTimer tm;
   // ---- the hierarchy ----
   const int max_levels = 12, coarsest_max = 800;
   std::vector<HostCsr> As, Ps;
@@ -1048,23 +1185,30 @@ int build_hierarchy(pmg_amg amg, HostCsr&& A0, size_t level0_len)
     for (int i = 0; i < A.n; ++i)
       PMG_REQUIRE(d[i] > 0.0, "pmg_amg_create: non-positive diagonal entry on level %d", (int)As.size() - 1);
     const double rho = 1.05 * lambda_max_jacobi(A, d, 20);
+    tm.lap("power method");
     lmaxs.push_back(rho);
     if (A.n <= coarsest_max || (int)As.size() >= max_levels)
       break;
     std::vector<int> agg;
     const int na = aggregate(A, d, theta, agg);
+    tm.lap("aggregation");
     if (na == 0 || na >= A.n)
       break; // nothing to coarsen
     HostCsr P = smoothed_prolongator(A, d, agg, na, 4.0 / (3.0 * rho));
+    tm.lap("smoothed prolongator");
     HostCsr R = transpose(P);
+    tm.lap("transpose");
     HostCsr AP = spgemm(A, P);
+    tm.lap("A P");
     HostCsr Ac = spgemm(R, AP);
+    tm.lap("R (A P)");
     Ps.push_back(std::move(P));
     As.push_back(std::move(Ac));
     theta *= 0.5;
   }
 
   const int L = (int)As.size();
+  tm.lap("(levels done)");
   amg->levels.resize(L);
   for (int l = 0; l < L; ++l)
   {
@@ -1101,6 +1245,7 @@ int build_hierarchy(pmg_amg amg, HostCsr&& A0, size_t level0_len)
       PMG_TRY(to_device(&amg->dense_inv, inv));
     }
   }
+  tm.lap("upload + dense inverse");
   amg->hA = std::move(As);
   amg->hP = std::move(Ps);
   amg->hlmax = lmaxs;
