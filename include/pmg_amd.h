@@ -134,6 +134,41 @@ int pmg_comm_size(pmg_comm comm);
 int pmg_layout_set_comm(pmg_layout l, pmg_comm comm, int32_t n_neighbors, const int32_t* neighbor_ranks,
                         const int32_t* send_counts, const int32_t* recv_counts);
 
+/* ---- halo windows: the neighbour exchange as direct stores into the neighbours' memory ----
+ * A second route for the exchange of src/vector.hpp:186-238 between the GPUs of one node, next to the grouped
+ * ncclSend / ncclRecv above: every rank owns a *window* of device memory which its neighbours map (hipIpc) and store
+ * their packed values into; arrival and consumption are signalled by counters in a small flag block, double-buffered.
+ * An exchange is two kernels on the compute stream (gather + store + signal; wait + copy + acknowledge): no second
+ * stream, no host work beyond the two launches, capturable into a hipGraph on any runtime.  The reductions still use
+ * the layout's communicator or callbacks.
+ *
+ *   pmg_window_alloc / _open / _close / _free : window memory (zeroed, fine-grained where the runtime offers it) and
+ *       its 64-byte interprocess handle; the caller passes the handles between the ranks by whatever means it has
+ *       (a file, MPI, torch.distributed.all_gather_object).  A rank that is its own neighbour passes its own pointers.
+ *   pmg_layout_window_describe : for a plan (per-neighbour counts, in the order of the index lists given to
+ *       pmg_layout_create) the size of the window in doubles and, per neighbour k, where in MY window k's values land
+ *       (fwd_offsets: owner -> ghost; rev_offsets: ghost -> owner).  The flag block has PMG_WINDOW_FLAG_WORDS uint64.
+ *   pmg_layout_set_windows : attaches my window and flag block and, per neighbour k, its mapped window and flag
+ *       block, the size of its window (what IT got from describe), the offsets IT got from describe for ME, and my
+ *       position in ITS neighbour list (nb_slot).  All memory must outlive the layout.
+ * Every rank must call every scatter of a layout in the same order.  A wait that exceeds PMG_WINDOW_TIMEOUT_MS
+ * (default 5000) ends the kernel and fails the next scatter of the layout with PMG_ERR_HIP. */
+#define PMG_WINDOW_HANDLE_BYTES 64
+#define PMG_WINDOW_MAX_NEIGHBORS 64
+#define PMG_WINDOW_FLAG_WORDS (4 * PMG_WINDOW_MAX_NEIGHBORS + 8)
+#define PMG_WINDOW_ERR_NO_ARRIVAL 1
+#define PMG_WINDOW_ERR_SLOT_BUSY 2
+int pmg_window_alloc(size_t bytes, void** ptr, char* handle /* [PMG_WINDOW_HANDLE_BYTES] */);
+int pmg_window_open(const char* handle, void** ptr);
+int pmg_window_close(void* ptr);
+int pmg_window_free(void* ptr);
+int pmg_layout_window_describe(int32_t n_neighbors, const int32_t* send_counts, const int32_t* recv_counts,
+                               int64_t* window_doubles, int64_t* fwd_offsets, int64_t* rev_offsets);
+int pmg_layout_set_windows(pmg_layout l, int32_t n_neighbors, const int32_t* send_counts, const int32_t* recv_counts,
+                           double* window, uint64_t* flags, double* const* nb_window, uint64_t* const* nb_flags,
+                           const int64_t* nb_window_doubles, const int64_t* nb_fwd_offset, const int64_t* nb_rev_offset,
+                           const int32_t* nb_slot);
+
 /* Vector::scatter_fwd_begin / scatter_fwd_end (src/vector.hpp:186-238): owner ->
  * ghost update of x; pack/unpack run on `stream` without host synchronisation. */
 int pmg_scatter_fwd_begin(pmg_layout l, const double* x, pmg_stream stream);

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("PMG_AMD_LIB") or os.path.join(_HERE, "lib", "libpmg_a
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)
 c_bp = C.POINTER(C.c_int8)
+c_lp = C.POINTER(C.c_int64)
 vp = C.c_void_p
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int, vp)
@@ -49,6 +50,15 @@ _SIGS = {
     "pmg_comm_rank": (C.c_int, [vp]),
     "pmg_comm_size": (C.c_int, [vp]),
     "pmg_layout_set_comm": (C.c_int, [vp, vp, C.c_int32, c_ip, c_ip, c_ip]),
+    "pmg_window_alloc": (C.c_int, [C.c_size_t, C.POINTER(vp), C.c_char_p]),
+    "pmg_window_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "pmg_window_close": (C.c_int, [vp]),
+    "pmg_window_free": (C.c_int, [vp]),
+    "pmg_layout_window_describe": (C.c_int, [C.c_int32, c_ip, c_ip, c_lp, c_lp, c_lp]),
+    "pmg_layout_set_windows": (
+        C.c_int,
+        [vp, C.c_int32, c_ip, c_ip, vp, vp, C.POINTER(vp), C.POINTER(vp), c_lp, c_lp, c_lp, c_ip],
+    ),
     "pmg_scatter_fwd_begin": (C.c_int, [vp, vp, vp]),
     "pmg_scatter_fwd_end": (C.c_int, [vp, vp, vp]),
     "pmg_scatter_rev_begin": (C.c_int, [vp, vp, vp]),

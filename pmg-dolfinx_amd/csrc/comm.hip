@@ -293,7 +293,7 @@ bool comm_capture_ready(pmg_layout l, bool with_allreduce)
 {
   if (!l->comm)
     return true;
-  if (!l->nb_rank.empty() && !l->exchanged_eagerly)
+  if (!l->win && !l->nb_rank.empty() && !l->exchanged_eagerly) // halo windows are plain kernels: nothing to warm up
     return false;
   return !with_allreduce || l->comm->reduced_eagerly;
 }

@@ -81,6 +81,7 @@ struct HandleGuard
 };
 
 struct pmg_comm_s;
+struct pmg_window_s;
 
 struct pmg_layout_s
 {
@@ -96,6 +97,9 @@ struct pmg_layout_s
   double *c_send = nullptr, *c_recv = nullptr;
   int32_t *send_pos = nullptr, *recv_pos = nullptr;
   std::vector<size_t> send_off, recv_off;
+  // halo windows (window.hip): when set, the neighbour exchange is direct stores into the neighbours' windows;
+  // the reductions still go through `comm` or the callbacks
+  pmg_window_s* win = nullptr;
   bool exchange_inline = false; // the exchange in flight was issued on the compute stream (graph capture)
   bool exchanged_eagerly = false; // an exchange of this layout has been issued outside a capture (comm_capture_ready)
   const int32_t* send_idx = nullptr;
@@ -124,6 +128,11 @@ int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s);
 int comm_exchange_end(pmg_layout l, hipStream_t s);
 int comm_allreduce(pmg_layout l, double* d_values, int n, bool max, hipStream_t s);
 bool comm_capture_ready(pmg_layout l, bool with_allreduce);
+
+// window.hip -- the exchange of a layout that has halo windows (x: the whole vector, owned entries first)
+int window_exchange_begin(pmg_layout l, bool reverse, const double* x, hipStream_t s);
+int window_exchange_end(pmg_layout l, bool reverse, double* x, hipStream_t s);
+void window_destroy(pmg_layout l);
 
 // Profiling ranges (roctx, bound at run time; no-ops when libroctx64 is absent).  The reference
 // annotates each CG iteration (src/amd_gpu.hpp:236-252, src/cg.hpp:174,219); here every phase of

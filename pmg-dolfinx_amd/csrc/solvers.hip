@@ -670,7 +670,7 @@ long long capture_config(pmg_multigrid mg)
     // halo: the caller's callbacks are host code inside the cycle.  The library's grouped ncclSend / ncclRecv are
     // captured on the capture stream itself (comm_exchange_begin; forking to the communicator's stream inside a
     // capture crashes RCCL 2.26).
-    if (l->exchange && !l->comm)
+    if (l->exchange && !l->comm && !l->win)
       return -1;
     // first use of a peer connection / of the collective must not fall inside a capture: eager until every level's
     // layout has exchanged once (and, with the replicated AMG's all-reduce, the communicator has reduced once)
@@ -685,6 +685,7 @@ long long capture_config(pmg_multigrid mg)
     mix((uint64_t)(uintptr_t)mg->ops[i]);
     mix((uint64_t)(uintptr_t)mg->smoothers[i]);
     mix((uint64_t)(uintptr_t)l->comm);
+    mix((uint64_t)(uintptr_t)l->win);
     if (i + 1 < mg->L)
       mix((uint64_t)(uintptr_t)mg->interps[i]);
     mix((uint64_t)mg->smoothers[i]->max_iter);

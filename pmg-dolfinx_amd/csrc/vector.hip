@@ -774,6 +774,7 @@ extern "C" int pmg_layout_destroy(pmg_layout l)
     (void)hipEventDestroy(l->ev_packed);
   if (l->ev_arrived)
     (void)hipEventDestroy(l->ev_arrived);
+  window_destroy(l);
   (void)hipFree(l->c_send);
   (void)hipFree(l->c_recv);
   (void)hipFree(l->send_pos);
@@ -795,6 +796,8 @@ extern "C" int pmg_layout_set_allreduce_max(pmg_layout l, pmg_allreduce_fn allre
 extern "C" int pmg_scatter_fwd_begin(pmg_layout l, const double* x, pmg_stream stream)
 {
   PMG_REQUIRE(l && x, "pmg_scatter_fwd_begin: NULL argument");
+  if (l->win)
+    return window_exchange_begin(l, false, x, S(stream));
   if (!l->comm && !l->exchange)
   {
     PMG_REQUIRE(l->n_send == 0 && l->n_recv == 0,
@@ -821,6 +824,8 @@ extern "C" int pmg_scatter_fwd_begin(pmg_layout l, const double* x, pmg_stream s
 extern "C" int pmg_scatter_fwd_end(pmg_layout l, double* x, pmg_stream stream)
 {
   PMG_REQUIRE(l && x, "pmg_scatter_fwd_end: NULL argument");
+  if (l->win)
+    return window_exchange_end(l, false, x, S(stream));
   if (!l->comm && !l->exchange)
     return PMG_OK; // single rank
   if (l->comm)
@@ -845,6 +850,8 @@ extern "C" int pmg_scatter_fwd_end(pmg_layout l, double* x, pmg_stream stream)
 extern "C" int pmg_scatter_rev_begin(pmg_layout l, const double* x, pmg_stream stream)
 {
   PMG_REQUIRE(l && x, "pmg_scatter_rev_begin: NULL argument");
+  if (l->win)
+    return window_exchange_begin(l, true, x, S(stream));
   if (!l->comm && !l->exchange)
   {
     PMG_REQUIRE(l->n_send == 0 && l->n_recv == 0,
@@ -872,6 +879,8 @@ extern "C" int pmg_scatter_rev_begin(pmg_layout l, const double* x, pmg_stream s
 extern "C" int pmg_scatter_rev_end(pmg_layout l, double* x, pmg_stream stream)
 {
   PMG_REQUIRE(l && x, "pmg_scatter_rev_end: NULL argument");
+  if (l->win)
+    return window_exchange_end(l, true, x, S(stream));
   if (!l->comm && !l->exchange)
     return PMG_OK; // single rank
   if (l->comm)

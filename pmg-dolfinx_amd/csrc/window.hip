@@ -1,0 +1,455 @@
+// Halo windows: the neighbour exchange as direct stores into the neighbours' memory.
+//
+// The second way the library can move a halo between the GPUs of one node (the first is the
+// grouped ncclSend / ncclRecv of comm.hip).  It replaces the same piece of the reference,
+// dolfinx's Scatterer over GPU-aware MPI (src/vector.hpp:186-238), but needs no transport at all
+// at run time: every rank owns a *window* (device memory exported with hipIpcGetMemHandle and
+// mapped by its neighbours, who reach it over xGMI) and
+//
+//   begin : ONE kernel on the compute stream gathers the owned values and stores them straight
+//           into the neighbours' windows, then raises an "arrived" flag in each neighbour's
+//           flag block;
+//   (the interior-cell kernels run on the compute stream meanwhile)
+//   end   : ONE kernel waits for the neighbours' "arrived" flags, copies the window into the
+//           ghost entries and raises a "consumed" flag at each neighbour.
+//
+// Two kernels per exchange, the same number as the pack / unpack pair of the RCCL route, and
+// nothing else: no second stream, no events, no ~115 us of host work per grouped RCCL call
+// (DESIGN.md section 6), no proxy thread, and the exchange is ordinary kernel launches to a
+// hipGraph capture on any runtime.
+//
+// Protocol (per layout and direction d: 0 = owner -> ghost, 1 = ghost -> owner).  Exchanges are
+// numbered 1, 2, ... on the device (a captured graph replays kernel arguments, so the number
+// cannot be one); exchange s uses slot s & 1 of every window.
+//   sender : waits until every neighbour has consumed exchange s - 2 (the previous tenant of the
+//            slot), stores, fences at system scope, and the last block to finish writes s to
+//            arrived[d][me] at every neighbour;
+//   receiver: every block waits for arrived[d][k] >= s from all neighbours k, fences, reads its
+//            own window; the last block to finish writes s to consumed[d][me] at every neighbour.
+// A rank can therefore run at most two exchanges ahead of a neighbour, and no wait can starve:
+// the waits are bounded (PMG_WINDOW_TIMEOUT_MS, default 5000) and a timeout is reported by the
+// next call on the layout instead of hanging the GPU.
+//
+// The reductions still need a collective: a layout with windows keeps its communicator (or its
+// callbacks) for those.
+#include "common.hpp"
+
+#include <cstdlib>
+#include <cstring>
+
+using namespace pmg;
+
+namespace
+{
+constexpr int NBMAX = PMG_WINDOW_MAX_NEIGHBORS;
+// flag block (uint64 words), written by the neighbours unless noted
+constexpr int F_ARRIVED = 0;           // [2][NBMAX]
+constexpr int F_CONSUMED = 2 * NBMAX;  // [2][NBMAX]
+constexpr int F_LOCAL = 4 * NBMAX;     // written by the owner only:
+constexpr int L_SENT = 0;              //   [2] number of the last exchange sent
+constexpr int L_GOT = 2;               //   [2] number of the last exchange received
+constexpr int L_PACK_DONE = 4;         //   [2] blocks of the running pack kernel that have finished
+constexpr int L_UNPACK_DONE = 6;       //   [2] the same for the unpack kernel
+static_assert(F_LOCAL + 8 == PMG_WINDOW_FLAG_WORDS, "flag block size");
+
+struct WindowDev // device copy of what the kernels need
+{
+  int n = 0;                // neighbours
+  double* win = nullptr;    // my window: [2 slots][stride]
+  uint64_t* flags = nullptr;
+  long long stride = 0, region[2] = {0, 0}; // start of the region direction d is received in
+  double* nb_win[NBMAX];
+  uint64_t* nb_flags[NBMAX];
+  long long nb_stride[NBMAX], nb_off[2][NBMAX];
+  int nb_slot[NBMAX];
+  int* err = nullptr; // pinned host memory: 0, or PMG_WINDOW_ERR_* | direction << 8
+  long long timeout_ticks = 0; // of wall_clock64 (100 MHz)
+};
+
+__device__ inline uint64_t load_sys(const uint64_t* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline void store_sys(uint64_t* p, uint64_t v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline uint64_t load_dev(const uint64_t* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Wait until *p >= target; false after the time limit (the caller records the error and goes on:
+// every wave of the grid still reaches its end).
+__device__ inline bool wait_flag(const uint64_t* p, uint64_t target, long long limit)
+{
+  if (load_sys(p) >= target)
+    return true;
+  const long long t0 = wall_clock64();
+  while (load_sys(p) < target)
+  {
+    __builtin_amdgcn_s_sleep(16);
+    if (wall_clock64() - t0 > limit)
+      return false;
+  }
+  return true;
+}
+
+// in[idx[i]] -> the window of neighbour ent_nb[i], place ent_j[i] of my segment there (forward: the send list
+// over the owned entries; reverse: the receive list over the ghost entries, `in` already offset)
+__global__ void window_put_kernel(const WindowDev* __restrict__ wp, int d, int n,
+                                  const int32_t* __restrict__ idx, const int32_t* __restrict__ ent_nb,
+                                  const int32_t* __restrict__ ent_j, const double* __restrict__ in)
+{
+  const WindowDev& w = *wp;
+  __shared__ uint64_t s_seq;
+  uint64_t* local = w.flags + F_LOCAL;
+  if (threadIdx.x < 64) // first wave: lane k looks after neighbour k
+  {
+    const uint64_t s = load_dev(&local[L_SENT + d]) + 1;
+    if ((int)threadIdx.x < w.n && s > 2)
+      if (!wait_flag(&w.flags[F_CONSUMED + d * NBMAX + threadIdx.x], s - 2, w.timeout_ticks))
+        *w.err = PMG_WINDOW_ERR_SLOT_BUSY | (d << 8);
+    if (threadIdx.x == 0)
+      s_seq = s;
+  }
+  __syncthreads();
+  const uint64_t s = s_seq;
+  const long long slot = (long long)(s & 1);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+  {
+    const int k = ent_nb[i];
+    w.nb_win[k][slot * w.nb_stride[k] + w.nb_off[d][k] + ent_j[i]] = in[idx[i]];
+  }
+  __threadfence_system(); // my stores are visible before my count is
+  __syncthreads();
+  __shared__ int s_last;
+  if (threadIdx.x == 0)
+  {
+    const unsigned long long prev = atomicAdd((unsigned long long*)&local[L_PACK_DONE + d], 1ull);
+    s_last = prev == (unsigned long long)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x < 64)
+  {
+    __threadfence_system(); // every block's stores (ordered before its count) before the flags
+    if ((int)threadIdx.x < w.n)
+      store_sys(&w.nb_flags[threadIdx.x][F_ARRIVED + d * NBMAX + w.nb_slot[threadIdx.x]], s);
+    if (threadIdx.x == 0)
+    {
+      __hip_atomic_store(&local[L_PACK_DONE + d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&local[L_SENT + d], s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// my window -> out[idx[i]] (assign: ghosts; add: owned entries)
+template <bool ADD>
+__global__ void window_get_kernel(const WindowDev* __restrict__ wp, int d, int n,
+                                  const int32_t* __restrict__ idx, const int32_t* __restrict__ pos,
+                                  double* __restrict__ out)
+{
+  const WindowDev& w = *wp;
+  __shared__ uint64_t s_seq;
+  uint64_t* local = w.flags + F_LOCAL;
+  if (threadIdx.x < 64)
+  {
+    const uint64_t e = load_dev(&local[L_GOT + d]) + 1;
+    if ((int)threadIdx.x < w.n)
+      if (!wait_flag(&w.flags[F_ARRIVED + d * NBMAX + threadIdx.x], e, w.timeout_ticks))
+        *w.err = PMG_WINDOW_ERR_NO_ARRIVAL | (d << 8);
+    if (threadIdx.x == 0)
+      s_seq = e;
+  }
+  __syncthreads();
+  __threadfence_system(); // acquire: nothing of the window is read before the flags were seen
+  const uint64_t e = s_seq;
+  const double* src = w.win + (long long)(e & 1) * w.stride + w.region[d];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+  {
+    // system scope: the value a neighbour stored, not a line this XCD's L2 kept from two exchanges ago
+    const double v = __hip_atomic_load(&src[pos[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (ADD)
+      atomicAdd(&out[idx[i]], v);
+    else
+      out[idx[i]] = v;
+  }
+  __syncthreads();
+  __shared__ int s_last;
+  if (threadIdx.x == 0)
+  {
+    const unsigned long long prev = atomicAdd((unsigned long long*)&local[L_UNPACK_DONE + d], 1ull);
+    s_last = prev == (unsigned long long)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x < 64)
+  {
+    if ((int)threadIdx.x < w.n)
+      store_sys(&w.nb_flags[threadIdx.x][F_CONSUMED + d * NBMAX + w.nb_slot[threadIdx.x]], e);
+    if (threadIdx.x == 0)
+    {
+      __hip_atomic_store(&local[L_UNPACK_DONE + d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&local[L_GOT + d], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+constexpr size_t ALIGN = 32; // doubles: every neighbour's segment starts on a 256-byte boundary
+
+// padded segment starts of one side of the plan; returns the padded length
+size_t segment_offsets(const int32_t* counts, int n, std::vector<size_t>& off)
+{
+  off.assign((size_t)n, 0);
+  size_t at = 0;
+  for (int k = 0; k < n; ++k)
+  {
+    off[(size_t)k] = at;
+    at = (at + (size_t)counts[k] + ALIGN - 1) / ALIGN * ALIGN;
+  }
+  return at;
+}
+
+constexpr int PUT_THREADS = 256;
+int put_blocks(int n)
+{
+  long long b = ((long long)n + PUT_THREADS - 1) / PUT_THREADS;
+  return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+} // namespace
+
+struct pmg_window_s
+{
+  WindowDev host;           // what the device copy holds
+  WindowDev* dev = nullptr; // device copy
+  int* err = nullptr;       // pinned
+  // per-entry tables of the two put directions: neighbour and place in its segment
+  int32_t *fwd_nb = nullptr, *fwd_j = nullptr, *rev_nb = nullptr, *rev_j = nullptr;
+  // places of the list entries in my own window regions
+  int32_t *recv_pos = nullptr, *send_pos = nullptr;
+};
+
+namespace pmg
+{
+void window_destroy(pmg_layout l)
+{
+  pmg_window_s* w = l->win;
+  if (!w)
+    return;
+  (void)hipFree(w->dev);
+  (void)hipHostFree(w->err);
+  for (int32_t* p : {w->fwd_nb, w->fwd_j, w->rev_nb, w->rev_j, w->recv_pos, w->send_pos})
+    (void)hipFree(p);
+  delete w;
+  l->win = nullptr;
+}
+
+static int window_check(pmg_layout l)
+{
+  const int e = *(volatile int*)l->win->err;
+  if (e == 0)
+    return PMG_OK;
+  const int d = e >> 8;
+  return fail(PMG_ERR_HIP,
+              (e & 0xff) == PMG_WINDOW_ERR_NO_ARRIVAL
+                  ? "halo window: a neighbour's data (%s) did not arrive within the time limit (PMG_WINDOW_TIMEOUT_MS)"
+                  : "halo window: a neighbour did not consume the previous exchange (%s) within the time limit "
+                    "(PMG_WINDOW_TIMEOUT_MS)",
+              d ? "ghost -> owner" : "owner -> ghost");
+}
+
+int window_exchange_begin(pmg_layout l, bool reverse, const double* x, hipStream_t s)
+{
+  pmg_window_s* w = l->win;
+  PMG_TRY(window_check(l));
+  if (w->host.n == 0)
+    return PMG_OK;
+  const int d = reverse ? 1 : 0;
+  const int n = reverse ? l->n_recv : l->n_send;
+  window_put_kernel<<<put_blocks(n), PUT_THREADS, 0, s>>>(w->dev, d, n, reverse ? l->recv_idx : l->send_idx,
+                                                          reverse ? w->rev_nb : w->fwd_nb,
+                                                          reverse ? w->rev_j : w->fwd_j,
+                                                          reverse ? x + l->size_local : x);
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+int window_exchange_end(pmg_layout l, bool reverse, double* x, hipStream_t s)
+{
+  pmg_window_s* w = l->win;
+  if (w->host.n == 0)
+    return PMG_OK;
+  if (reverse)
+    window_get_kernel<true><<<put_blocks(l->n_send), PUT_THREADS, 0, s>>>(w->dev, 1, l->n_send, l->send_idx,
+                                                                          w->send_pos, x);
+  else
+    window_get_kernel<false><<<put_blocks(l->n_recv), PUT_THREADS, 0, s>>>(w->dev, 0, l->n_recv, l->recv_idx,
+                                                                           w->recv_pos, x + l->size_local);
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+} // namespace pmg
+
+// ---- window memory ----
+static_assert(sizeof(hipIpcMemHandle_t) == PMG_WINDOW_HANDLE_BYTES, "pmg window handle size");
+
+extern "C" int pmg_window_alloc(size_t bytes, void** ptr, char* handle)
+{
+  PMG_REQUIRE(ptr && handle && bytes > 0, "pmg_window_alloc: bad argument");
+  void* p = nullptr;
+  // fine-grained: stores of another GPU must be visible to a kernel that is already running here
+  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess)
+  {
+    (void)hipGetLastError();
+    PMG_HIP(hipMalloc(&p, bytes));
+  }
+  e = hipMemset(p, 0, bytes);
+  if (e == hipSuccess)
+    e = hipDeviceSynchronize();
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess)
+    e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess)
+  {
+    (void)hipFree(p);
+    return fail(PMG_ERR_HIP, "pmg_window_alloc: %s", hipGetErrorString(e));
+  }
+  std::memcpy(handle, &h, sizeof(h));
+  *ptr = p;
+  return PMG_OK;
+}
+
+extern "C" int pmg_window_open(const char* handle, void** ptr)
+{
+  PMG_REQUIRE(ptr && handle, "pmg_window_open: NULL argument");
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle, sizeof(h));
+  PMG_HIP(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
+  return PMG_OK;
+}
+
+extern "C" int pmg_window_close(void* ptr)
+{
+  if (ptr)
+    PMG_HIP(hipIpcCloseMemHandle(ptr));
+  return PMG_OK;
+}
+
+extern "C" int pmg_window_free(void* ptr)
+{
+  if (ptr)
+    PMG_HIP(hipFree(ptr));
+  return PMG_OK;
+}
+
+extern "C" int pmg_layout_window_describe(int32_t n_neighbors, const int32_t* send_counts,
+                                          const int32_t* recv_counts, int64_t* window_doubles,
+                                          int64_t* fwd_offsets, int64_t* rev_offsets)
+{
+  PMG_REQUIRE(n_neighbors >= 0 && n_neighbors <= NBMAX,
+              "halo windows serve at most %d neighbours per rank (this one has %d): use the RCCL exchange", NBMAX,
+              n_neighbors);
+  PMG_REQUIRE(window_doubles && (n_neighbors == 0 || (send_counts && recv_counts && fwd_offsets && rev_offsets)),
+              "pmg_layout_window_describe: NULL argument");
+  std::vector<size_t> so, ro;
+  const size_t rlen = segment_offsets(recv_counts, n_neighbors, ro);
+  const size_t slen = segment_offsets(send_counts, n_neighbors, so);
+  for (int k = 0; k < n_neighbors; ++k)
+  {
+    fwd_offsets[k] = (int64_t)ro[(size_t)k];          // where neighbour k's owned values land (my ghosts)
+    rev_offsets[k] = (int64_t)(rlen + so[(size_t)k]); // where neighbour k's ghost values land (my owned entries)
+  }
+  const size_t stride = rlen + slen;
+  *window_doubles = (int64_t)(2 * (stride ? stride : ALIGN));
+  return PMG_OK;
+}
+
+extern "C" int pmg_layout_set_windows(pmg_layout l, int32_t n_neighbors, const int32_t* send_counts,
+                                      const int32_t* recv_counts, double* window, uint64_t* flags,
+                                      double* const* nb_window, uint64_t* const* nb_flags,
+                                      const int64_t* nb_window_doubles, const int64_t* nb_fwd_offset,
+                                      const int64_t* nb_rev_offset, const int32_t* nb_slot)
+{
+  PMG_REQUIRE(l && window && flags, "pmg_layout_set_windows: NULL argument");
+  PMG_REQUIRE(n_neighbors >= 0 && n_neighbors <= NBMAX,
+              "halo windows serve at most %d neighbours per rank (this one has %d): use the RCCL exchange", NBMAX,
+              n_neighbors);
+  PMG_REQUIRE(n_neighbors == 0 || (send_counts && recv_counts && nb_window && nb_flags && nb_window_doubles
+                                   && nb_fwd_offset && nb_rev_offset && nb_slot),
+              "pmg_layout_set_windows: neighbour arrays missing");
+  long long ns = 0, nr = 0;
+  for (int k = 0; k < n_neighbors; ++k)
+  {
+    PMG_REQUIRE(send_counts[k] >= 0 && recv_counts[k] >= 0, "pmg_layout_set_windows: negative count");
+    PMG_REQUIRE(nb_window[k] && nb_flags[k], "pmg_layout_set_windows: neighbour %d has no window", k);
+    PMG_REQUIRE(nb_slot[k] >= 0 && nb_slot[k] < NBMAX, "pmg_layout_set_windows: bad slot %d", nb_slot[k]);
+    // what I store must fit the neighbour's window: it receives my send list in its forward region ...
+    PMG_REQUIRE(nb_fwd_offset[k] >= 0 && nb_rev_offset[k] >= 0
+                    && 2 * (nb_fwd_offset[k] + send_counts[k]) <= nb_window_doubles[k]
+                    && 2 * (nb_rev_offset[k] + recv_counts[k]) <= nb_window_doubles[k],
+                "pmg_layout_set_windows: my segment does not fit neighbour %d's window", k);
+    ns += send_counts[k];
+    nr += recv_counts[k];
+  }
+  PMG_REQUIRE(ns == l->n_send && nr == l->n_recv,
+              "pmg_layout_set_windows: per-neighbour counts (%lld, %lld) do not add up to the layout's n_send, "
+              "n_recv (%d, %d)", ns, nr, l->n_send, l->n_recv);
+  window_destroy(l);
+  auto* w = new pmg_window_s;
+  l->win = w;
+  std::vector<size_t> so, ro;
+  const size_t rlen = segment_offsets(recv_counts, n_neighbors, ro);
+  const size_t slen = segment_offsets(send_counts, n_neighbors, so);
+  WindowDev& h = w->host;
+  h.n = n_neighbors;
+  h.win = window;
+  h.flags = flags;
+  h.stride = (long long)(rlen + slen ? rlen + slen : ALIGN);
+  h.region[0] = 0;
+  h.region[1] = (long long)rlen;
+  for (int k = 0; k < n_neighbors; ++k)
+  {
+    h.nb_win[k] = nb_window[k];
+    h.nb_flags[k] = nb_flags[k];
+    h.nb_stride[k] = nb_window_doubles[k] / 2;
+    h.nb_off[0][k] = nb_fwd_offset[k];
+    h.nb_off[1][k] = nb_rev_offset[k];
+    h.nb_slot[k] = nb_slot[k];
+  }
+  long long ms = 5000;
+  if (const char* e = std::getenv("PMG_WINDOW_TIMEOUT_MS"))
+    ms = std::atoll(e) > 0 ? std::atoll(e) : ms;
+  h.timeout_ticks = ms * 100000ll; // wall_clock64 counts at 100 MHz
+  PMG_HIP(hipHostMalloc(&w->err, sizeof(int), hipHostMallocMapped));
+  *w->err = 0;
+  h.err = w->err;
+  PMG_HIP(hipMalloc(&w->dev, sizeof(WindowDev)));
+  PMG_HIP(hipMemcpy(w->dev, &h, sizeof(WindowDev), hipMemcpyHostToDevice));
+  // per-entry tables
+  auto upload = [](const std::vector<int32_t>& v, int32_t** d) -> int {
+    PMG_HIP(hipMalloc(d, sizeof(int32_t) * (v.empty() ? 1 : v.size())));
+    if (!v.empty())
+      PMG_HIP(hipMemcpy(*d, v.data(), sizeof(int32_t) * v.size(), hipMemcpyHostToDevice));
+    return PMG_OK;
+  };
+  std::vector<int32_t> nb, j, pos;
+  auto side = [&](const int32_t* counts, const std::vector<size_t>& off, size_t base) {
+    nb.clear(), j.clear(), pos.clear();
+    for (int k = 0; k < n_neighbors; ++k)
+      for (int32_t i = 0; i < counts[k]; ++i)
+      {
+        nb.push_back(k);
+        j.push_back(i);
+        pos.push_back((int32_t)(base + off[(size_t)k] + (size_t)i));
+      }
+  };
+  side(send_counts, so, 0); // send list: put forward, get reverse (my reverse region is addressed from region[1])
+  PMG_TRY(upload(nb, &w->fwd_nb));
+  PMG_TRY(upload(j, &w->fwd_j));
+  PMG_TRY(upload(pos, &w->send_pos));
+  side(recv_counts, ro, 0);
+  PMG_TRY(upload(nb, &w->rev_nb));
+  PMG_TRY(upload(j, &w->rev_j));
+  PMG_TRY(upload(pos, &w->recv_pos));
+  return PMG_OK;
+}

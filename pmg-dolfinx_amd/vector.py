@@ -36,9 +36,10 @@ class TorchComm:
 
     native = None
 
-    def __init__(self, group=None, always_exchange=False):
+    def __init__(self, group=None, always_exchange=False, halo="exchange"):
         dist = _dist()
         self.group = group
+        self.halo = halo  # "windows": the halo moves through pmg_layout_set_windows, the reductions through this
         self.initialized = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.initialized else 1
         self.rank = dist.get_rank(group) if self.initialized else 0
@@ -86,6 +87,14 @@ class TorchComm:
             dist.all_to_all_single(host_out, host_in, outsp, insp, group=self.group)
             dst.copy_(host_out)
 
+    def gather_objects(self, obj):
+        """Set-up time: every rank's picklable ``obj``, in rank order."""
+        if not self.initialized:
+            return [obj]
+        out = [None] * self.world
+        _dist().all_gather_object(out, obj, group=self.group)
+        return out
+
     def allreduce(self, layout, host, op):
         import torch
 
@@ -115,11 +124,12 @@ class RcclComm:
     by the library with no callback into Python.  One process per GPU; ``unique_id`` from rank 0
     reaches the others through the caller's bootstrap (here: ``torch.distributed``)."""
 
-    def __init__(self, rank: int, size: int, unique_id: bytes):
+    def __init__(self, rank: int, size: int, unique_id: bytes, halo="exchange"):
         if len(unique_id) != 128:
             raise ValueError("unique id must be 128 bytes")
         self.rank, self.world = int(rank), int(size)
         self.distributed = True
+        self.halo = halo  # "windows": the halo as stores into the neighbours' windows, RCCL for the reductions only
         h = vp()
         call("pmg_comm_create", C.byref(h), self.rank, self.world, C.c_char_p(unique_id))
         self.native = h
@@ -132,7 +142,7 @@ class RcclComm:
         return buf.raw
 
     @classmethod
-    def from_torch(cls, group=None, device=None):
+    def from_torch(cls, group=None, device=None, halo="exchange"):
         """Bootstrap over an initialised ``torch.distributed`` group (any backend)."""
         import torch
 
@@ -140,7 +150,7 @@ class RcclComm:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         payload = [cls.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(payload, src=0, group=group, device=device)
-        c = cls(rank, world, payload[0])
+        c = cls(rank, world, payload[0], halo=halo)
         c._host = TorchComm(group)  # set-up-time host exchanges (numpy arrays) only
         return c
 
@@ -152,6 +162,13 @@ class RcclComm:
         if self._host is None:
             raise RuntimeError("RcclComm without a host-side bootstrap group cannot move host arrays")
         return self._host.all_to_all_host(layout, send, recv_count)
+
+    def gather_objects(self, obj):
+        if self._host is None:
+            if self.world == 1:
+                return [obj]
+            raise RuntimeError("RcclComm without a host-side bootstrap group cannot pass window handles")
+        return self._host.gather_objects(obj)
 
     def __del__(self):
         try:
@@ -227,6 +244,9 @@ class Layout:
             rc = np.ascontiguousarray(self.recv_counts, dtype=np.int32)
             call("pmg_layout_set_comm", h, native, nb.size, nb.ctypes.data_as(_lib.c_ip),
                  sc.ctypes.data_as(_lib.c_ip), rc.ctypes.data_as(_lib.c_ip))
+        self._windows = None
+        if self.distributed and getattr(self.comm, "halo", "exchange") == "windows":
+            self._windows = HaloWindows(self)
         if hasattr(self.comm, "register"):
             self.comm.register(self)
 
@@ -280,8 +300,90 @@ class Layout:
             if self._handle is not None:
                 _lib.lib().pmg_layout_destroy(self._handle)
                 self._handle = None
+            if getattr(self, "_windows", None) is not None:
+                self._windows.release()
         except Exception:
             pass
+
+
+class HaloWindows:
+    """Window memory of one layout and the neighbours' mapped windows (``pmg_window_*``,
+    ``pmg_layout_set_windows``): the 64-byte interprocess handles and the per-neighbour offsets
+    travel once, at set-up, as picklable objects over the communicator's bootstrap group."""
+
+    FLAG_WORDS = 4 * 64 + 8
+
+    def __init__(self, layout: "Layout"):
+        L = layout
+        comm = L.comm
+        n = len(L.neighbors)
+        sc = np.ascontiguousarray(L.send_counts, dtype=np.int32)
+        rc = np.ascontiguousarray(L.recv_counts, dtype=np.int32)
+        doubles = C.c_int64()
+        fwd, rev = np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int64)
+        call("pmg_layout_window_describe", n, sc.ctypes.data_as(_lib.c_ip), rc.ctypes.data_as(_lib.c_ip),
+             C.byref(doubles), fwd.ctypes.data_as(_lib.c_lp), rev.ctypes.data_as(_lib.c_lp))
+        self.window, wh = self._alloc(8 * doubles.value)
+        self.flags, fh = self._alloc(8 * self.FLAG_WORDS)
+        self._opened = []
+        import os
+
+        # (a window of this very process -- a rank that is its own neighbour, ranks that are threads -- is used
+        # through its pointer: a process cannot open its own interprocess handle)
+        mine = {"neighbors": list(L.neighbors), "doubles": int(doubles.value), "fwd": fwd[:n].tolist(),
+                "rev": rev[:n].tolist(), "window": wh, "flags": fh, "pid": os.getpid(),
+                "pointers": (self.window.value, self.flags.value)}
+        everyone = comm.gather_objects(mine)
+        me = int(comm.rank)
+        mapped = {me: (self.window, self.flags)}
+        nb_win, nb_flags = (vp * max(n, 1))(), (vp * max(n, 1))()
+        nb_doubles, nb_fwd, nb_rev = (np.zeros(max(n, 1), np.int64) for _ in range(3))
+        nb_slot = np.zeros(max(n, 1), np.int32)
+        seen = {}
+        for k, r in enumerate(L.neighbors):
+            info = everyone[r]
+            # the j-th time rank r appears in my list pairs with the j-th time I appear in r's list
+            j = seen.get(r, 0)
+            seen[r] = j + 1
+            slots = [i for i, q in enumerate(info["neighbors"]) if q == me]
+            if j >= len(slots):
+                raise ValueError(f"rank {r} does not list rank {me} as a neighbour as often as rank {me} lists it")
+            slot = slots[j]
+            if r not in mapped:
+                if info["pid"] == os.getpid():
+                    mapped[r] = (vp(info["pointers"][0]), vp(info["pointers"][1]))
+                else:
+                    mapped[r] = (self._open(info["window"]), self._open(info["flags"]))
+            nb_win[k], nb_flags[k] = (m.value for m in mapped[r])
+            nb_doubles[k], nb_fwd[k], nb_rev[k], nb_slot[k] = info["doubles"], info["fwd"][slot], info["rev"][slot], slot
+        call("pmg_layout_set_windows", L.handle, n, sc.ctypes.data_as(_lib.c_ip), rc.ctypes.data_as(_lib.c_ip),
+             self.window, self.flags, nb_win, nb_flags, nb_doubles.ctypes.data_as(_lib.c_lp),
+             nb_fwd.ctypes.data_as(_lib.c_lp), nb_rev.ctypes.data_as(_lib.c_lp), nb_slot.ctypes.data_as(_lib.c_ip))
+        # nobody stores into a window its owner could still free on a failed set-up
+        comm.gather_objects(True)
+
+    @staticmethod
+    def _alloc(nbytes):
+        p, h = vp(), C.create_string_buffer(64)
+        call("pmg_window_alloc", nbytes, C.byref(p), h)
+        return p, h.raw
+
+    def _open(self, handle):
+        p = vp()
+        call("pmg_window_open", C.c_char_p(handle), C.byref(p))
+        self._opened.append(p)
+        return p
+
+    def release(self):
+        """After the layout is gone: unmap the neighbours' windows, free mine."""
+        lib = _lib.lib()
+        for p in self._opened:
+            lib.pmg_window_close(p)
+        self._opened = []
+        for p in (self.window, self.flags):
+            if p is not None:
+                lib.pmg_window_free(p)
+        self.window = self.flags = None
 
 
 class Vector:

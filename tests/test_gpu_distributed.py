@@ -214,24 +214,28 @@ def _assert_rank_results(res):
             out["rep_full_its"], out["rep_its"], out["rep_dist_vs_full"])
 
 
-def _worker_body(rank, world, port, n, dims, orders):
+def _worker_body(rank, world, port, n, dims, orders, halo="exchange"):
     import torch
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import pmg_dolfinx_amd as pm
 
         torch.cuda.set_device(0)
-        return _rank_checks(pm, rank, world, n, dims, orders)
+        comm = pm.TorchComm(halo="windows") if halo == "windows" else None
+        out = _rank_checks(pm, rank, world, n, dims, orders, comm=comm)
+        dist.barrier()  # nobody frees a window a neighbour may still acknowledge into
+        return out
     finally:
         dist.destroy_process_group()
 
 
-def _worker(rank, world, port, n, dims, orders, q):
-    _reporting(_worker_body)(rank, world, port, n, dims, orders, q)
+def _worker(rank, world, port, n, dims, orders, *rest):
+    _reporting(_worker_body)(rank, world, port, n, dims, orders, *rest)
 
 
 @pytest.mark.parametrize("dims,n", [((1, 1, 2), (3, 4, 8)), ((2, 1, 1), (6, 3, 4)), ((1, 2, 2), (3, 4, 6))])
@@ -245,6 +249,23 @@ def test_ranks_share_one_gpu(dims, n, built):
     orders = (1, 2, 4) if dims[0] * dims[1] * dims[2] == 2 else (1, 2)
     world = dims[0] * dims[1] * dims[2]
     _assert_rank_results(_run_ranks(_worker, world, (n, dims, orders)))
+
+
+@pytest.mark.parametrize("dims,n", [((1, 1, 2), (3, 4, 8)), ((1, 2, 2), (3, 4, 6))])
+def test_ranks_share_one_gpu_through_halo_windows(dims, n, built):
+    """The same checks with the halo moved by the library's windows: every rank (a process) stores its packed
+    values straight into its neighbours' interprocess-mapped windows and waits on their flags -- the whole protocol of
+    window.hip between real processes (two and four: the box admits six on its GPU, the test runner included), with the one GPU standing in for the
+    peers' GPUs (the reductions stay on the gloo callbacks).  Not run with the ranks as threads of one process: eight
+    streams share the process's four hardware queues, and a kernel waiting for a flag at the head of a queue would
+    hold back the very kernel that raises it."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    orders = (1, 2, 4) if dims[0] * dims[1] * dims[2] == 2 else (1, 2)
+    world = dims[0] * dims[1] * dims[2]
+    _assert_rank_results(_run_ranks(_worker, world, (n, dims, orders, "windows")))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -414,7 +435,7 @@ def _rccl_worker(rank, world, port, q):
     _reporting(_rccl_worker_body)(rank, world, port, q)
 
 
-def _native_worker_body(rank, world, port):
+def _native_worker_body(rank, world, port, halo="exchange"):
     """The library's own communicator (pmg_comm: RCCL bound at run time, grouped ncclSend/ncclRecv on
     its own stream, ncclAllReduce on device scalars) with one rank that is its own neighbour -- RCCL
     needs one GPU per rank, so on this box that is the whole of the native path that can run; the
@@ -425,7 +446,7 @@ def _native_worker_body(rank, world, port):
     from oracle import pmg_oracle as po
 
     torch.cuda.set_device(0)
-    comm = pm.RcclComm(0, 1, pm.RcclComm.unique_id())
+    comm = pm.RcclComm(0, 1, pm.RcclComm.unique_id(), halo=halo)
     rng = np.random.default_rng(6)
     n, m = 120_000, 40_000
     send = rng.permutation(n)[:m].astype(np.int32)
@@ -482,16 +503,17 @@ def _native_worker_body(rank, world, port):
     return out
 
 
-def _native_worker(rank, world, port, q):
-    _reporting(_native_worker_body)(rank, world, port, q)
+def _native_worker(rank, world, port, *rest):
+    _reporting(_native_worker_body)(rank, world, port, *rest)
 
 
-def test_native_rccl_communicator_single_rank(built):
+@pytest.mark.parametrize("halo", ["exchange", "windows"])
+def test_native_rccl_communicator_single_rank(built, halo):
     import torch
 
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    (out,) = _run_ranks(_native_worker, 1, ())
+    (out,) = _run_ranks(_native_worker, 1, (halo,))
     for s in ("default", "side"):
         assert out[s + "_fwd"]
         assert out[s + "_rev"] < 1e-14 and out[s + "_dot"] < 1e-13 and out[s + "_linf"]
@@ -511,7 +533,7 @@ def test_rccl_branch_single_rank(built):
     assert np.isfinite(out["rnorm"]) and out["rnorm"] > 0
 
 
-def _self_partner_graph_body(rank, world, port):
+def _self_partner_graph_body(rank, world, port, halo="exchange"):
     """A rank that is its own halo partner: every scatter packs, sends to itself through the library's
     communicator and unpacks real halo volumes.  The numbers are not the multi-rank solution, but they
     are a deterministic function of what the exchange moves -- so the same cycles replayed as a hipGraph
@@ -522,7 +544,7 @@ def _self_partner_graph_body(rank, world, port):
     from pmg_dolfinx_amd import problem
 
     torch.cuda.set_device(0)
-    native = pm.RcclComm(0, 1, pm.RcclComm.unique_id())
+    native = pm.RcclComm(0, 1, pm.RcclComm.unique_id(), halo=halo)
     orig = problem.make_layout
 
     def self_layout(comm, reverse=False):
@@ -584,16 +606,17 @@ def _self_partner_graph_body(rank, world, port):
     return out
 
 
-def _self_partner_graph_worker(rank, world, port, q):
-    _reporting(_self_partner_graph_body)(rank, world, port, q)
+def _self_partner_graph_worker(rank, world, port, *rest):
+    _reporting(_self_partner_graph_body)(rank, world, port, *rest)
 
 
-def test_graph_replay_captures_the_rccl_exchange(built):
+@pytest.mark.parametrize("halo", ["exchange", "windows"])
+def test_graph_replay_captures_the_rccl_exchange(built, halo):
     import torch
 
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    (out,) = _run_ranks(_self_partner_graph_worker, 1, ())
+    (out,) = _run_ranks(_self_partner_graph_worker, 1, (halo,))
     assert all(g > 0 for g in out["ghosts"])
     assert out["replays"] >= 3  # captured on the first cycle, replayed afterwards
     assert out["graph_vs_eager"] < 1e-12  # tolerance: atomic-order noise of the merged launches
@@ -602,7 +625,7 @@ def test_graph_replay_captures_the_rccl_exchange(built):
     assert out["reordered_lists"] < 1e-12
 
 
-def _segments_body(rank, world, port):
+def _segments_body(rank, world, port, halo="exchange"):
     """Several neighbour segments (here: three, all to the rank itself) through the library's communicator: the
     per-neighbour offsets of the padded staging buffers, forward and reverse."""
     import torch
@@ -610,7 +633,7 @@ def _segments_body(rank, world, port):
     import pmg_dolfinx_amd as pm
 
     torch.cuda.set_device(0)
-    comm = pm.RcclComm(0, 1, pm.RcclComm.unique_id())
+    comm = pm.RcclComm(0, 1, pm.RcclComm.unique_id(), halo=halo)
     n_local, counts = 5000, [37, 1001, 64]  # odd lengths: every later segment would start unaligned without padding
     m = sum(counts)
     rng = np.random.default_rng(3)
@@ -636,16 +659,17 @@ def _segments_body(rank, world, port):
     return out
 
 
-def _segments_worker(rank, world, port, q):
-    _reporting(_segments_body)(rank, world, port, q)
+def _segments_worker(rank, world, port, *rest):
+    _reporting(_segments_body)(rank, world, port, *rest)
 
 
-def test_native_exchange_with_several_segments(built):
+@pytest.mark.parametrize("halo", ["exchange", "windows"])
+def test_native_exchange_with_several_segments(built, halo):
     import torch
 
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    (out,) = _run_ranks(_segments_worker, 1, ())
+    (out,) = _run_ranks(_segments_worker, 1, (halo,))
     assert out["fwd"] == 0.0
     assert out["rev"] < 1e-14
 
@@ -654,7 +678,7 @@ def test_native_exchange_with_several_segments(built):
 # Real RCCL between GPUs: runs wherever at least two devices are visible (the one-GPU test box skips it).
 # "add one 2-rank test of forward and reverse exchange plus a captured cycle, to run once when a
 # multi-GPU box is available".
-def _multi_gpu_body(rank, world, port, n, dims, orders):
+def _multi_gpu_body(rank, world, port, n, dims, orders, halo="exchange"):
     import torch
     import torch.distributed as dist
 
@@ -666,7 +690,7 @@ def _multi_gpu_body(rank, world, port, n, dims, orders):
     try:
         import pmg_dolfinx_amd as pm
 
-        comm = pm.RcclComm.from_torch(device=torch.device("cuda", rank))
+        comm = pm.RcclComm.from_torch(device=torch.device("cuda", rank), halo=halo)
         assert comm.size() == world
         out = _rank_checks(pm, rank, world, n, dims, orders, comm=comm)
         # forward + reverse scatter through the communicator against the partition's own lists
@@ -699,6 +723,7 @@ def _multi_gpu_body(rank, world, port, n, dims, orders):
         H.mg.set_graph(False)
         out["graph_replays"] = r1 - r0
         out["graph_vs_eager"] = float(np.abs(xg - xe).max() / np.abs(xe).max())
+        dist.barrier()  # (windows) nobody frees a window a neighbour may still acknowledge into
         return out
     finally:
         dist.destroy_process_group()
@@ -712,22 +737,91 @@ def dist_all_ghost_globals(dist, lv):
     return gathered
 
 
-def _multi_gpu_worker(rank, world, port, n, dims, orders, q):
-    _reporting(_multi_gpu_body)(rank, world, port, n, dims, orders, q)
+def _multi_gpu_worker(rank, world, port, n, dims, orders, *rest):
+    _reporting(_multi_gpu_body)(rank, world, port, n, dims, orders, *rest)
 
 
+@pytest.mark.parametrize("halo", ["exchange", "windows"])
 @pytest.mark.parametrize("dims,n", [((1, 1, 1), (4, 4, 4)), ((1, 1, 2), (4, 4, 8)), ((2, 2, 2), (6, 6, 6))])
-def test_native_rccl_between_gpus(dims, n, built):
+def test_native_rccl_between_gpus(dims, n, halo, built):
     """(1, 1, 1) is the rehearsal of this test's own code on a one-GPU box: a torch nccl group and a library
-    communicator of one rank, no halo."""
+    communicator of one rank, no halo.  halo = "windows": the exchange as stores into the peer GPUs' windows over
+    xGMI, RCCL for the reductions only."""
     import torch
 
     world = dims[0] * dims[1] * dims[2]
     if torch.cuda.device_count() < world:
         pytest.skip(f"needs {world} GPUs, {torch.cuda.device_count()} visible")
-    res = _run_ranks(_multi_gpu_worker, world, (n, dims, (1, 2, 4)), timeout=600)
+    res = _run_ranks(_multi_gpu_worker, world, (n, dims, (1, 2, 4), halo), timeout=600)
     if world > 1:
         _assert_rank_results(res)
     for out in res:
         assert out["fwd_ok"] and out["rev_err"] == 0.0
         assert out["graph_replays"] >= 3 and out["graph_vs_eager"] < 1e-12
+
+
+def _window_timeout_body(rank, world, port):
+    """A neighbour that never answers: the waits of the window kernels are bounded, every wave reaches its end, and
+    the next scatter of the layout reports what happened instead of the GPU hanging."""
+    import ctypes as C
+
+    import torch
+
+    os.environ["PMG_WINDOW_TIMEOUT_MS"] = "200"
+    import pmg_dolfinx_amd as pm
+    from pmg_dolfinx_amd import _lib
+    from pmg_dolfinx_amd.vector import HaloWindows
+
+    torch.cuda.set_device(0)
+    n, m = 1000, 100
+    # a layout with one neighbour whose window and flags nobody serves
+    send = torch.arange(m, dtype=torch.int32, device="cuda")
+    h = _lib.vp()
+    sbuf, rbuf = torch.zeros(m, dtype=torch.float64, device="cuda"), torch.zeros(m, dtype=torch.float64, device="cuda")
+    _lib.call("pmg_layout_create", C.byref(h), n, m, m, _lib.ptr(send), _lib.ptr(sbuf), m, _lib.ptr(send),
+              _lib.ptr(rbuf), _lib.EXCHANGE_FN(), _lib.ALLREDUCE_FN(), _lib.vp(0))
+    cnt = np.array([m], dtype=np.int32)
+    doubles, fwd, rev = C.c_int64(), np.zeros(1, np.int64), np.zeros(1, np.int64)
+    _lib.call("pmg_layout_window_describe", 1, cnt.ctypes.data_as(_lib.c_ip), cnt.ctypes.data_as(_lib.c_ip),
+              C.byref(doubles), fwd.ctypes.data_as(_lib.c_lp), rev.ctypes.data_as(_lib.c_lp))
+    mine = [HaloWindows._alloc(8 * doubles.value)[0], HaloWindows._alloc(8 * HaloWindows.FLAG_WORDS)[0]]
+    peer = [HaloWindows._alloc(8 * doubles.value)[0], HaloWindows._alloc(8 * HaloWindows.FLAG_WORDS)[0]]
+    nbw, nbf = (_lib.vp * 1)(peer[0].value), (_lib.vp * 1)(peer[1].value)
+    nd = np.array([doubles.value], np.int64)
+    slot = np.zeros(1, np.int32)
+    _lib.call("pmg_layout_set_windows", h, 1, cnt.ctypes.data_as(_lib.c_ip), cnt.ctypes.data_as(_lib.c_ip), mine[0],
+              mine[1], nbw, nbf, nd.ctypes.data_as(_lib.c_lp), fwd.ctypes.data_as(_lib.c_lp),
+              rev.ctypes.data_as(_lib.c_lp), slot.ctypes.data_as(_lib.c_ip))
+    x = torch.zeros(n + m, dtype=torch.float64, device="cuda")
+    st = _lib.current_stream()
+    import time
+
+    t0 = time.time()
+    _lib.call("pmg_scatter_fwd_begin", h, _lib.ptr(x), st)
+    _lib.call("pmg_scatter_fwd_end", h, _lib.ptr(x), st)  # waits for an arrival that never comes
+    torch.cuda.synchronize()
+    out = {"seconds": time.time() - t0}
+    try:
+        _lib.call("pmg_scatter_fwd_begin", h, _lib.ptr(x), st)
+        out["error"] = ""
+    except RuntimeError as e:
+        out["error"] = str(e)
+    torch.cuda.synchronize()
+    _lib.lib().pmg_layout_destroy(h)
+    for p in mine + peer:
+        _lib.lib().pmg_window_free(p)
+    return out
+
+
+def _window_timeout_worker(rank, world, port, q):
+    _reporting(_window_timeout_body)(rank, world, port, q)
+
+
+def test_a_halo_window_wait_is_bounded(built):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    (out,) = _run_ranks(_window_timeout_worker, 1, ())
+    assert 0.15 < out["seconds"] < 5.0, out
+    assert "did not arrive within the time limit" in out["error"], out
