@@ -24,6 +24,8 @@ struct RankOptions
   int rank = 0;
   std::array<int, 3> ranks = {1, 1, 1};
   bool native_comm = false; // one rank through the RCCL communicator anyway
+  bool windows = false;     // --halo windows: the halo as stores into the neighbours' windows, RCCL for the reductions
+  pmg_amd::Halo halo() const { return windows ? pmg_amd::Halo::windows : pmg_amd::Halo::exchange; }
   std::string id_file = "/tmp/pmg_amd_comm_id";
   int size() const { return ranks[0] * ranks[1] * ranks[2]; }
 };

@@ -112,7 +112,7 @@ void solve(const Options& o)
     if (comm)
       maps[i] = std::make_shared<const common::IndexMap>(lv.size_local, lv.num_ghosts, lv.send_indices,
                                                          lv.recv_indices, comm, lv.neighbors, lv.send_counts,
-                                                         lv.recv_counts);
+                                                         lv.recv_counts, o.halo());
     else
       maps[i] = std::make_shared<const common::IndexMap>(lv.size_local, lv.num_ghosts);
     if (i == V.size() - 1) // :97 (finest space)
@@ -371,6 +371,13 @@ int main(int argc, char** argv)
         o.rank = std::atoi(next());
       else if (!std::strcmp(argv[i], "--native-comm")) // one rank through the RCCL communicator anyway
         o.native_comm = true;
+      else if (!std::strcmp(argv[i], "--halo"))
+      {
+        const std::string how = next();
+        if (how != "windows" && how != "exchange")
+          throw std::runtime_error("--halo exchange | windows");
+        o.windows = how == "windows";
+      }
       else if (!std::strcmp(argv[i], "--id-file"))
         o.id_file = next();
       else if (!std::strcmp(argv[i], "--output"))
@@ -381,7 +388,8 @@ int main(int argc, char** argv)
       {
         std::cout << "usage: pmg [--n cells_per_direction | --ndofs N_per_rank] [--orders 1,2,4] [--smoother-its K]\n"
                      "           [--cycles C] [--pcg [--random-rhs]] [--amg | --amg-cycles N | --coarse-cg] [--graph]\n"
-                     "           [--ranks px,py,pz [--rank r] [--id-file F]] [--native-comm] [--output FILE]\n"
+                     "           [--ranks px,py,pz [--rank r] [--id-file F]] [--native-comm] [--halo exchange|windows]\n"
+                     "           [--output FILE]\n"
                      "           [--check-partition px,py,pz]\n";
         return !std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h") ? 0 : 2;
       }

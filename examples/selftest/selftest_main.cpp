@@ -214,6 +214,61 @@ int main()
       (void)hipStreamDestroy(cs);
     }
 
+    // Halo windows with this rank as its own neighbour (pmg_layout_set_windows through the adapter): forward scatters,
+    // eager and replayed from a hipGraph, and the reverse scatter.
+    {
+      auto comm = std::make_shared<const Communicator>(0, 1, Communicator::unique_id());
+      const std::int32_t nb[1] = {0}, cnt[1] = {m};
+      auto wmap = std::make_shared<IndexMap>(n, m, send, recv, comm, nb, cnt, cnt, pmg_amd::Halo::windows);
+      DeviceVector xw(wmap, 1);
+      bool ok_w = true;
+      for (int rep = 0; rep < 5; ++rep) // more exchanges than window slots
+      {
+        std::vector<double> mod(a);
+        for (int j = 0; j < m; ++j)
+          mod[send[j]] = a[send[j]] + rep;
+        xw.copy_from_host(mod);
+        xw.scatter_fwd_begin();
+        xw.scatter_fwd_end();
+        std::vector<double> gw = xw.data_copy();
+        for (int j = 0; j < m; ++j)
+          ok_w = ok_w && gw[n + j] == mod[send[j]];
+      }
+      CHECK(ok_w);
+      hipStream_t cs;
+      bool hip_ok = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess;
+      CHECK(hipDeviceSynchronize() == hipSuccess);
+      hip_ok = hip_ok && hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) == hipSuccess;
+      bool lib_ok = pmg_scatter_fwd_begin(wmap->layout(), xw.mutable_array().data(), (pmg_stream)cs) == PMG_OK;
+      lib_ok = lib_ok && pmg_scatter_fwd_end(wmap->layout(), xw.mutable_array().data(), (pmg_stream)cs) == PMG_OK;
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      hip_ok = hip_ok && hipStreamEndCapture(cs, &graph) == hipSuccess && graph != nullptr;
+      hip_ok = hip_ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      CHECK(hip_ok && lib_ok);
+      if (hip_ok && lib_ok)
+        for (int rep = 0; rep < 3; ++rep) // the exchange number lives on the device: every replay is a new exchange
+        {
+          std::vector<double> mod(a);
+          for (int j = 0; j < m; ++j)
+            mod[send[j]] = a[send[j]] - rep;
+          xw.copy_from_host(mod);
+          CHECK(hipDeviceSynchronize() == hipSuccess);
+          CHECK(hipGraphLaunch(exec, cs) == hipSuccess);
+          CHECK(hipStreamSynchronize(cs) == hipSuccess);
+          std::vector<double> gw = xw.data_copy();
+          bool same = true;
+          for (int j = 0; j < m; ++j)
+            same = same && gw[n + j] == mod[send[j]];
+          CHECK(same);
+        }
+      if (exec)
+        (void)hipGraphExecDestroy(exec);
+      if (graph)
+        (void)hipGraphDestroy(graph);
+      (void)hipStreamDestroy(cs);
+    }
+
     // compute_boundary_cells: 4 cells of 2 dofs, 3 owned cells, 5 owned dofs
     std::vector<std::int32_t> dm = {0, 1, 2, 5, 3, 4, 0, 1};
     auto [lc, bc] = compute_boundary_cells(dm, 3, 4, 2, 5);

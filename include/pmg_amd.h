@@ -129,6 +129,9 @@ int pmg_comm_destroy(pmg_comm comm);
  * forked into the capture), 0 if this process's HIP runtime cannot end such a capture (7.0.x: unbounded recursion in
  * hipStreamEndCapture) and the captured exchange is issued on the capturing stream instead. */
 int pmg_comm_capture_overlaps(void);
+/* Set-up helper, blocking (where the reference's set-up calls MPI_Allgather): `bytes` bytes of host memory from every
+ * rank, in rank order, into recv[size * bytes] on every rank. */
+int pmg_comm_allgather(pmg_comm comm, const void* send, size_t bytes, void* recv);
 int pmg_comm_rank(pmg_comm comm);
 int pmg_comm_size(pmg_comm comm);
 int pmg_layout_set_comm(pmg_layout l, pmg_comm comm, int32_t n_neighbors, const int32_t* neighbor_ranks,

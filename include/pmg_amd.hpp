@@ -39,8 +39,11 @@
 #include <thrust/execution_policy.h>
 #include <thrust/transform.h>
 
+#include <unistd.h>
+
 #include <array>
 #include <cstdint>
+#include <map>
 #include <memory>
 #include <span>
 #include <stdexcept>
@@ -141,9 +144,26 @@ public:
   int rank() const { return pmg_comm_rank(_c); }
   int size() const { return pmg_comm_size(_c); }
   pmg_comm handle() const { return _c; }
+  /// Set-up time: one trivially copyable record from every rank, in rank order (MPI_Allgather's role).
+  template <typename R>
+  std::vector<R> allgather(const R& mine) const
+  {
+    static_assert(std::is_trivially_copyable_v<R>);
+    std::vector<R> all((std::size_t)size());
+    check(pmg_comm_allgather(_c, &mine, sizeof(R), all.data()));
+    return all;
+  }
 
 private:
   pmg_comm _c = nullptr;
+};
+
+/// How the halo of an IndexMap with a communicator travels: grouped ncclSend / ncclRecv, or direct stores into the
+/// neighbours' windows (pmg_layout_set_windows; RCCL then serves the reductions only).
+enum class Halo
+{
+  exchange,
+  windows
 };
 
 /// Stand-in for dolfinx::common::IndexMap + common::Scatterer on this path:
@@ -172,7 +192,7 @@ public:
   IndexMap(std::int32_t size_local, std::int32_t num_ghosts, std::span<const std::int32_t> send_indices,
            std::span<const std::int32_t> recv_indices, std::shared_ptr<const Communicator> comm,
            std::span<const std::int32_t> neighbors, std::span<const std::int32_t> send_counts,
-           std::span<const std::int32_t> recv_counts)
+           std::span<const std::int32_t> recv_counts, Halo halo = Halo::exchange)
       : IndexMap(size_local, num_ghosts, send_indices, recv_indices)
   {
     if (neighbors.size() != send_counts.size() || neighbors.size() != recv_counts.size())
@@ -180,10 +200,19 @@ public:
     _comm = std::move(comm);
     check(pmg_layout_set_comm(_layout, _comm->handle(), (std::int32_t)neighbors.size(), neighbors.data(),
                               send_counts.data(), recv_counts.data()));
+    if (halo == Halo::windows)
+      attach_windows(neighbors, send_counts, recv_counts);
   }
   IndexMap(const IndexMap&) = delete;
   IndexMap& operator=(const IndexMap&) = delete;
-  ~IndexMap() { pmg_layout_destroy(_layout); }
+  ~IndexMap()
+  {
+    pmg_layout_destroy(_layout);
+    for (void* p : _opened)
+      pmg_window_close(p);
+    pmg_window_free(_window);
+    pmg_window_free(_flags);
+  }
 
   std::int32_t size_local() const { return _size_local; }
   std::int32_t num_ghosts() const { return _num_ghosts; }
@@ -193,11 +222,86 @@ public:
   std::span<double> recv_buffer() { return _recv.span(); }
 
 private:
+  // What a rank tells the others about its window (collective over the communicator: every rank constructs its
+  // IndexMaps in the same order).
+  struct WindowRecord
+  {
+    std::int32_t n = 0, pid = 0;
+    std::int32_t neighbors[PMG_WINDOW_MAX_NEIGHBORS] = {};
+    std::int64_t doubles = 0, fwd[PMG_WINDOW_MAX_NEIGHBORS] = {}, rev[PMG_WINDOW_MAX_NEIGHBORS] = {};
+    char window[PMG_WINDOW_HANDLE_BYTES] = {}, flags[PMG_WINDOW_HANDLE_BYTES] = {};
+    void *window_ptr = nullptr, *flags_ptr = nullptr; // meaningful inside process `pid` only
+  };
+  void attach_windows(std::span<const std::int32_t> neighbors, std::span<const std::int32_t> send_counts,
+                      std::span<const std::int32_t> recv_counts)
+  {
+    const int n = (int)neighbors.size();
+    auto mine = std::make_unique<WindowRecord>();
+    check(pmg_layout_window_describe(n, send_counts.data(), recv_counts.data(), &mine->doubles, mine->fwd, mine->rev));
+    check(pmg_window_alloc(sizeof(double) * (std::size_t)mine->doubles, &_window, mine->window));
+    check(pmg_window_alloc(sizeof(std::uint64_t) * PMG_WINDOW_FLAG_WORDS, &_flags, mine->flags));
+    mine->n = n;
+    mine->pid = (std::int32_t)getpid();
+    mine->window_ptr = _window;
+    mine->flags_ptr = _flags;
+    for (int k = 0; k < n; ++k)
+      mine->neighbors[k] = neighbors[k];
+    const std::vector<WindowRecord> all = _comm->allgather(*mine);
+    const int me = _comm->rank();
+    std::vector<double*> nb_window((std::size_t)n);
+    std::vector<std::uint64_t*> nb_flags((std::size_t)n);
+    std::vector<std::int64_t> nb_doubles((std::size_t)n), nb_fwd((std::size_t)n), nb_rev((std::size_t)n);
+    std::vector<std::int32_t> nb_slot((std::size_t)n);
+    std::map<int, std::pair<void*, void*>> mapped;
+    std::map<int, int> seen;
+    for (int k = 0; k < n; ++k)
+    {
+      const int r = neighbors[k];
+      const WindowRecord& info = all.at((std::size_t)r);
+      // the j-th time rank r appears in my list pairs with the j-th time I appear in r's list
+      int j = seen[r]++, slot = -1;
+      for (int i = 0; i < info.n; ++i)
+        if (info.neighbors[i] == me && j-- == 0)
+        {
+          slot = i;
+          break;
+        }
+      if (slot < 0)
+        throw std::runtime_error("IndexMap: a neighbour does not list this rank as its neighbour");
+      if (!mapped.count(r))
+      {
+        if (info.pid == mine->pid) // my own window (a rank that is its own periodic neighbour)
+          mapped[r] = {info.window_ptr, info.flags_ptr};
+        else
+        {
+          void *w = nullptr, *f = nullptr;
+          check(pmg_window_open(info.window, &w));
+          _opened.push_back(w);
+          check(pmg_window_open(info.flags, &f));
+          _opened.push_back(f);
+          mapped[r] = {w, f};
+        }
+      }
+      nb_window[(std::size_t)k] = static_cast<double*>(mapped[r].first);
+      nb_flags[(std::size_t)k] = static_cast<std::uint64_t*>(mapped[r].second);
+      nb_doubles[(std::size_t)k] = info.doubles;
+      nb_fwd[(std::size_t)k] = info.fwd[slot];
+      nb_rev[(std::size_t)k] = info.rev[slot];
+      nb_slot[(std::size_t)k] = slot;
+    }
+    check(pmg_layout_set_windows(_layout, n, send_counts.data(), recv_counts.data(), static_cast<double*>(_window),
+                                 static_cast<std::uint64_t*>(_flags), nb_window.data(), nb_flags.data(),
+                                 nb_doubles.data(), nb_fwd.data(), nb_rev.data(), nb_slot.data()));
+    (void)_comm->allgather(me); // every rank has mapped its neighbours before anybody stores
+  }
+
   std::int32_t _size_local, _num_ghosts;
   device_array<std::int32_t> _send_idx, _recv_idx;
   device_array<double> _send, _recv;
   std::shared_ptr<const Communicator> _comm;
   pmg_layout _layout = nullptr;
+  void *_window = nullptr, *_flags = nullptr;
+  std::vector<void*> _opened;
 };
 
 /// compute_boundary_cells (src/mesh.hpp:105-143) on flattened inputs: cells that touch

@@ -43,6 +43,7 @@ struct RcclApi
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                             hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -73,6 +74,7 @@ int load_rccl()
   PMG_SYM(Send, "ncclSend")
   PMG_SYM(Recv, "ncclRecv")
   PMG_SYM(AllReduce, "ncclAllReduce")
+  PMG_SYM(AllGather, "ncclAllGather")
   PMG_SYM(GetErrorString, "ncclGetErrorString")
 #undef PMG_SYM
   g_rccl.handle = h;
@@ -143,6 +145,32 @@ extern "C" int pmg_comm_destroy(pmg_comm c)
   if (c->stream)
     (void)hipStreamDestroy(c->stream);
   delete c;
+  return PMG_OK;
+}
+
+// Set-up helper (the reference's set-up uses MPI for this): `bytes` bytes of host memory from every rank, in rank
+// order, into recv[nranks * bytes] on every rank.  Blocking; not for the hot path.
+extern "C" int pmg_comm_allgather(pmg_comm c, const void* send, size_t bytes, void* recv)
+{
+  PMG_REQUIRE(c && send && recv && bytes > 0, "pmg_comm_allgather: bad argument");
+  char *d_in = nullptr, *d_out = nullptr;
+  PMG_HIP(hipMalloc(&d_in, bytes));
+  hipError_t e = hipMalloc(&d_out, bytes * (size_t)c->nranks);
+  if (e == hipSuccess)
+    e = hipMemcpy(d_in, send, bytes, hipMemcpyHostToDevice);
+  ncclResult_t r = ncclSuccess;
+  if (e == hipSuccess)
+  {
+    r = g_rccl.AllGather(d_in, d_out, bytes, ncclInt8, c->comm, c->stream);
+    if (r == ncclSuccess)
+      e = hipStreamSynchronize(c->stream);
+    if (r == ncclSuccess && e == hipSuccess)
+      e = hipMemcpy(recv, d_out, bytes * (size_t)c->nranks, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  PMG_NCCL(r);
+  PMG_HIP(e);
   return PMG_OK;
 }
 

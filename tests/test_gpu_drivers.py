@@ -204,8 +204,10 @@ def test_vector_update_driver(built, tmp_path):
 
 
 def test_pmg_driver_graph_replay(built, tmp_path):
-    """--graph: the timed cycles run as hipGraph replays, also on a layout with the RCCL communicator."""
-    for extra in ([], ["--native-comm", "--id-file", str(tmp_path / "id")]):
+    """--graph: the timed cycles run as hipGraph replays, also on a layout with the RCCL communicator (and with
+    --halo windows: the adapter's window bootstrap over the communicator, here without neighbours)."""
+    for extra in ([], ["--native-comm", "--id-file", str(tmp_path / "id")],
+                  ["--native-comm", "--halo", "windows", "--id-file", str(tmp_path / "id")]):
         out = run("pmg_main", "--n", 6, "--orders", "1,2,4", "--cycles", 2, "--graph", *extra)
         assert "(hipGraph replays)" in out
         ref = run("pmg_main", "--n", 6, "--orders", "1,2,4", "--cycles", 2, *extra)

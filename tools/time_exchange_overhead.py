@@ -1,7 +1,7 @@
 """Cost of the halo path on ONE GPU: the config-2 V-cycle of rank 0 of a 1x1x2 split (64^3 owned cells plus
 the ghost layer; every scatter packs / exchanges / unpacks the real halo volume, ~2 MB at p4) with the rank as
-its own partner, through (a) the library's RCCL communicator, (b) callbacks into torch.distributed, against
-(c) the same brick without any exchange.  The numerics are meaningless (ghosts receive the wrong owned values);
+its own partner, through (a) the library's RCCL communicator, (b) the library's halo windows, (c) callbacks into
+torch.distributed, against (d) the same brick without any exchange.  The numerics are meaningless (ghosts receive the wrong owned values);
 the timings are not: host issue time per cycle, cycle time, i.e. what the exchange costs before any xGMI
 link is involved.   usage: python tools/time_exchange_overhead.py"""
 import os, sys, time
@@ -55,6 +55,15 @@ H = build()
 print("library RCCL communicator: %.3f ms per cycle (host issue time %.3f ms)" % cycle_ms(H))
 H.mg.set_graph(True)
 print("  the same through a hipGraph (exchange captured on the compute stream): %.3f ms per cycle (host issue time %.3f ms), %d replays"
+      % (*cycle_ms(H), H.mg.graph_replays()))
+H.mg.set_graph(False)
+del H
+windows = pm.RcclComm(0, 1, pm.RcclComm.unique_id(), halo="windows")
+problem.make_layout = self_layout(lambda: windows)
+H = build()
+print("halo windows (direct stores + flags): %.3f ms per cycle (host issue time %.3f ms)" % cycle_ms(H))
+H.mg.set_graph(True)
+print("  the same through a hipGraph: %.3f ms per cycle (host issue time %.3f ms), %d replays"
       % (*cycle_ms(H), H.mg.graph_replays()))
 H.mg.set_graph(False)
 del H
