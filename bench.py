@@ -95,6 +95,12 @@ def parse_args(argv=None):
     ap.add_argument("--exchange", choices=["native", "torch"], default="native",
                     help="N > 1: halo + reductions on the library's own RCCL communicator (default) or through "
                          "torch.distributed callbacks")
+    ap.add_argument("--halo", choices=["exchange", "windows"], default="exchange",
+                    help="N > 1 with the library's communicator: the halo as grouped ncclSend/ncclRecv (default) or as "
+                         "direct stores into the neighbours' IPC-mapped windows (pmg_layout_set_windows; RCCL then "
+                         "serves the reductions only).  The windows are validated between processes sharing one GPU "
+                         "(tests/test_gpu_distributed.py), not yet between GPUs -- hence opt-in; either way the first "
+                         "thing a multi-rank run does is check a forward scatter against the partition's own index map")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaled config-3 measurement")
     ap.add_argument("--graph-exchange", action="store_true",
                     help="N > 1 with the library's communicator: additionally time the cycles replayed as a hipGraph "
@@ -209,7 +215,7 @@ def main():
     comm, comm_note = None, None
     if multi and args.exchange == "native":
         try:
-            comm = pm.RcclComm.from_torch(device=torch.device("cuda", local_rank))
+            comm = pm.RcclComm.from_torch(device=torch.device("cuda", local_rank), halo=args.halo)
         except Exception as e:  # e.g. no librccl to bind: every rank fails alike; the callback route still is RCCL
             comm_note = f"native communicator unavailable ({type(e).__name__}: {e}); torch.distributed callbacks"
             log(f"[rank {rank}] {comm_note}")
@@ -229,6 +235,20 @@ def main():
     log(f"[rank {rank}] setup {time.time() - t0:.1f}s dims={dims} n_global={n_global} "
         f"local dofs={[lv.size_local for lv in H.levels]} ghosts={[lv.num_ghosts for lv in H.levels]} "
         f"lmax={[round(e[1], 6) for e in H.eig_ranges]}")
+    if multi:
+        # the halo moves what the partition says it moves, on every level, before anything is timed: owned entries
+        # carry their global index, the ghosts must come back with theirs
+        for lv, lay in zip(H.levels, H.layouts):
+            v = pm.Vector(lay)
+            loc = np.full(lv.ndofs, -1.0)
+            loc[: lv.size_local] = lv.local_to_global[: lv.size_local]
+            v.data.copy_(torch.from_numpy(loc))
+            v.scatter_fwd()
+            good = torch.tensor([1 if np.array_equal(v.data_copy(), np.asarray(lv.local_to_global, dtype=np.float64))
+                                 else 0], device="cuda")
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            if int(good.item()) == 0:
+                raise LaunchError(f"[rank {rank}] the halo exchange ({args.halo}) does not reproduce the index map")
     P = orders[-1]
     fine_dofs_global = H.part.global_ndofs(P)
     b = H.rhs[-1]
@@ -342,7 +362,9 @@ def main():
             "levels": list(reversed(orders)),
             "cheb_iterations": args.cheb,
             "partition": "x".join(str(d) for d in dims) + " bricks, 1 ghost-cell layer",
-            "exchange": ("library RCCL communicator (grouped send/recv, device all-reduce)" if comm is not None
+            "exchange": (("library halo windows (direct stores into the neighbours' IPC-mapped memory), RCCL device "
+                          "all-reduce" if args.halo == "windows" else
+                          "library RCCL communicator (grouped send/recv, device all-reduce)") if comm is not None
                          else (comm_note or "torch.distributed callbacks")) if multi else "none (single rank)",
             "stiffness_launches_per_cycle": {f"p{p}": c for p, c in zip(orders, counts)},
             # ranks of the communicator the halo and the reductions really ran on (pmg_comm_size of the library's
