@@ -228,6 +228,27 @@ def _worker_body(rank, world, port, n, dims, orders, halo="exchange"):
         torch.cuda.set_device(0)
         comm = pm.TorchComm(halo="windows") if halo == "windows" else None
         out = _rank_checks(pm, rank, world, n, dims, orders, comm=comm)
+        if halo == "windows":
+            # the same cycles replayed as a hipGraph: no host in the loop, so the ranks drift apart as far as the
+            # protocol lets them (two exchanges) -- the exchange numbers kept on the device and the "consumed" counters
+            # are what keeps the replays correct
+            H = pm.PoissonHierarchy(n, orders, kappa=2.0, cheb_its=3, proc_dims=dims, rank=rank, size=world, warp=warp,
+                                    comm=comm)
+
+            def cycles(graph):
+                H.mg.set_graph(graph)
+                x = H.new_vector()
+                x.set(0.0)
+                for _ in range(8):
+                    H.mg.apply(H.rhs[-1], x)
+                torch.cuda.synchronize()
+                return x.data_copy()[: H.levels[-1].size_local].copy(), H.mg.graph_replays()
+
+            xe, r0 = cycles(False)
+            xg, r1 = cycles(True)
+            H.mg.set_graph(False)
+            out["graph_replays"] = r1 - r0
+            out["graph_vs_eager"] = float(np.abs(xg - xe).max() / np.abs(xe).max())
         dist.barrier()  # nobody frees a window a neighbour may still acknowledge into
         return out
     finally:
@@ -265,7 +286,10 @@ def test_ranks_share_one_gpu_through_halo_windows(dims, n, built):
         pytest.skip("no GPU")
     orders = (1, 2, 4) if dims[0] * dims[1] * dims[2] == 2 else (1, 2)
     world = dims[0] * dims[1] * dims[2]
-    _assert_rank_results(_run_ranks(_worker, world, (n, dims, orders, "windows")))
+    res = _run_ranks(_worker, world, (n, dims, orders, "windows"))
+    _assert_rank_results(res)
+    for out in res:
+        assert out["graph_replays"] >= 7 and out["graph_vs_eager"] < 1e-12, (out["graph_replays"], out["graph_vs_eager"])
 
 
 # ---------------------------------------------------------------------------------------------
