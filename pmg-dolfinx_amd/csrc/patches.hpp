@@ -42,21 +42,55 @@ inline constexpr PatchShape patch_shape(int P)
   switch (P)
   {
   case 1:
-    return {4, 4, 8, 256};   // M = 5*5*9   = 225
+#ifdef PMG_P1_SHAPE
+    return {PMG_P1_SHAPE};
+#else
+    return {4, 4, 16, 448};   // M = 5*5*17  = 425 (round 3: 21.2 us against 23.3 for 4x4x8 at 64^3)
+#endif
   case 2:
-    return {4, 4, 8, 1408};   // M = 9*9*17  = 1377 (measured 12 % faster than 2x2x8)
+#ifdef PMG_P2_SHAPE
+    return {PMG_P2_SHAPE};
+#else
+    return {4, 4, 16, 2688};  // M = 9*9*33  = 2673 (round 3, 64^3 / 128^3: 82 / 580 us against 97 / 660 for 4x4x8,
+                              // 134 / 997 for 2x2x8, 82 / 626 for 4x4x32: profiles/kernel_tuning_r03.md section 11)
+#endif
   case 3:
+#ifdef PMG_P3_SHAPE
+    return {PMG_P3_SHAPE};
+#else
     return {2, 2, 8, 1280};   // M = 7*7*25  = 1225
+#endif
   case 4:
+#ifdef PMG_P4_SHAPE
+    return {PMG_P4_SHAPE};
+#else
     return {2, 2, 8, 2688};   // M = 9*9*33  = 2673
+#endif
   case 5:
+#ifdef PMG_P5_SHAPE
+    return {PMG_P5_SHAPE};
+#else
     return {2, 2, 4, 2560};   // M = 11*11*21 = 2541
+#endif
   case 6:
-    return {2, 2, 2, 2240};   // M = 13^3    = 2197
+#ifdef PMG_P6_SHAPE
+    return {PMG_P6_SHAPE};
+#else
+    return {1, 1, 8, 2432};   // M = 7*7*49  = 2401 (round 3, 43^3: 463 us against 515 for 2x2x2, 478 for 1x2x4 / 1x1x4,
+                              // 481 for 1x1x12, 536 for 1x2x8, 630 for 1x1x16)
+#endif
   case 7:
-    return {2, 2, 2, 3392};   // M = 15^3    = 3375
+#ifdef PMG_P7_SHAPE
+    return {PMG_P7_SHAPE};
+#else
+    return {2, 2, 3, 4976};   // M = 15*15*22 = 4950 (round 3, 36^3: 389 us against 413-424 for 2x2x2, 403 for 1x1x8)
+#endif
   default:
+#ifdef PMG_P8_SHAPE
+    return {PMG_P8_SHAPE};
+#else
     return {1, 1, 4, 2688};   // M = 9*9*33  = 2673
+#endif
   }
 }
 
