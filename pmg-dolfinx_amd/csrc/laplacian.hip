@@ -103,14 +103,30 @@ struct Shape
   static constexpr PatchShape PS = patch_shape(P);
   static constexpr int K = PS.bx * PS.by * PS.bz; // cells per patch
   static constexpr int MAXM = PS.max_m;           // patch dofs held in LDS
-  // a wave takes CW whole cells, a lane one (a, b) column
+  // An item is CW whole cells worked on by WPC waves, a lane one (a, b) column of one of the cells.  Where nd^2 divides
+  // 64 badly a wave per cell group idles many lanes (P = 5: 36 of 64, P = 8: 81 of 128); there four waves share an
+  // item of 7 (P = 5: 252 of 256 lanes) or 3 (P = 8: 243 of 256) cells and exchange their slices through workgroup
+  // barriers instead of wave-private fences -- worth it only with ONE item per workgroup, i.e. patches of exactly CW
+  // cells (round 3, profiles/kernel_tuning_r03.md section 12: P = 5 532 -> 466 us, P = 8 495 -> 421; P = 4 and P = 6,
+  // 78 % of the lanes busy, lose or gain nothing this way).
   static constexpr int NQ2 = ND * ND;
-  static constexpr int CW = NQ2 <= 64 ? 64 / NQ2 : 1;
-  static constexpr int WPC = (NQ2 + 63) / 64;      // waves that share one cell (2 at P = 8)
+  static constexpr bool SHARED_ITEM = P == 5 || P == 8;
+#ifdef PMG_ITEM_P // experiment: -DPMG_ITEM_P=<degree> -DPMG_ITEM_CW=<cells> -DPMG_ITEM_WPC=<waves>
+  static constexpr int CW = P == PMG_ITEM_P ? PMG_ITEM_CW : (NQ2 <= 64 ? 64 / NQ2 : 1);
+  static constexpr int WPC = P == PMG_ITEM_P ? PMG_ITEM_WPC : (NQ2 + 63) / 64;
+#else
+  static constexpr int CW = P == 5 ? 7 : P == 8 ? 3 : (NQ2 <= 64 ? 64 / NQ2 : 1);
+  static constexpr int WPC = SHARED_ITEM ? 4 : (NQ2 + 63) / 64; // waves that share one item
+#endif
+  static_assert(CW * NQ2 <= 64 * WPC, "an item's columns need a lane each");
   static constexpr int ITEMS = (K + CW - 1) / CW;  // wave-items per full patch
   // measured (profiles/kernel_roofline_r01.md, profiles/kernel_tuning_r02.md): 4 waves and more
   // workgroups per CU for the register-heavy degrees and P = 3, 8 waves otherwise
+#ifdef PMG_NWMAX_P
+  static constexpr int NWMAX = P == PMG_NWMAX_P ? PMG_NWMAX_V : ((P == 3 || P == 5 || P == 6 || P == 8) ? 4 : 8);
+#else
   static constexpr int NWMAX = (P == 3 || P == 5 || P == 6 || P == 8) ? 4 : 8;
+#endif
   static constexpr int NG = ITEMS < NWMAX / WPC ? ITEMS : NWMAX / WPC; // items in flight per workgroup
   static constexpr int NW = NG * WPC;                                  // waves per workgroup
   static constexpr int WTHREADS = NW * 64;
@@ -168,7 +184,10 @@ __device__ inline void jacobian(const double* __restrict__ xgeom,
 //     P = 8) follow each other in the order the group consumes them, across its items.  The group streams them
 //     through a ring of LDS slots with LDS-direct loads (stiffness_ring_kernel below).
 __host__ __device__ constexpr bool gflat(int nd) { return nd == 3; } // P = 2 only
-__host__ __device__ constexpr int gcw(int nd) { return nd * nd <= 64 ? 64 / (nd * nd) : 1; }
+__host__ __device__ constexpr int gcw(int nd) // cells of an item (Shape<P>::CW)
+{
+  return nd == 6 ? 7 : nd == 9 ? 3 : nd * nd <= 64 ? 64 / (nd * nd) : 1;
+}
 __host__ __device__ constexpr int gls(int nd) { return ((3 * gcw(nd) * nd * nd + 7) / 8) * 8; } // layer stride
 // ring kernel configuration per degree: item groups per workgroup, ring depth in (item, layer) blocks; depth 0 = the
 // degree runs on the column kernel with register-held G.  ALL degrees do: the ring kernel is parity-green (every
@@ -533,7 +552,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   double* q_s = sq + wave * WL + cw * NQ2;  // this cell's slices
   double* gr_s = sgr + wave * WL + cw * NQ2;
   double* gs_s = sgs + wave * WL + cw * NQ2;
-  const int items = WPC > 1 ? ((nc + NG - 1) / NG) * NG : (nc + CW - 1) / CW;
+  const int items = WPC > 1 ? (((nc + CW - 1) / CW + NG - 1) / NG) * NG : (nc + CW - 1) / CW;
   auto slice_sync = [] {
     if constexpr (WPC > 1)
       lds_barrier();

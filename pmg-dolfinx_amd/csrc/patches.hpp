@@ -70,7 +70,7 @@ inline constexpr PatchShape patch_shape(int P)
 #ifdef PMG_P5_SHAPE
     return {PMG_P5_SHAPE};
 #else
-    return {2, 2, 4, 2560};   // M = 11*11*21 = 2541
+    return {1, 1, 7, 1344};   // M = 6*6*36  = 1296: one item of 7 cells per workgroup (laplacian.hip, Shape)
 #endif
   case 6:
 #ifdef PMG_P6_SHAPE
@@ -89,7 +89,7 @@ inline constexpr PatchShape patch_shape(int P)
 #ifdef PMG_P8_SHAPE
     return {PMG_P8_SHAPE};
 #else
-    return {1, 1, 4, 2688};   // M = 9*9*33  = 2673
+    return {1, 1, 3, 2048};   // M = 9*9*25  = 2025: one item of 3 cells per workgroup (laplacian.hip, Shape)
 #endif
   }
 }

@@ -80,8 +80,10 @@ def test_apply_parity_all_degrees(pm, P, mesh):
     assert _relerr(d.data_copy(), A.diag_inverse()) < 1e-12
 
 
-@pytest.mark.parametrize("P,n", [(1, (8, 8, 16)), (2, (4, 4, 16)), (3, (4, 4, 8)), (4, (4, 4, 8)), (5, (4, 4, 4)),
-                                 (6, (2, 4, 4)), (7, (2, 2, 4)), (8, (2, 2, 8))])
+@pytest.mark.parametrize("P,n", [(1, (8, 8, 16)), (2, (4, 4, 16)), (3, (4, 4, 8)), (4, (4, 4, 8)), (5, (4, 4, 14)),
+                                 (6, (2, 4, 8)), (7, (2, 2, 6)), (8, (2, 2, 6)),
+                                 # ... and meshes whose patches are all cut short (P = 5: 4 of the 7 cells of an item)
+                                 (5, (4, 4, 4)), (6, (2, 4, 4)), (7, (2, 2, 4)), (8, (2, 2, 8))])
 def test_apply_parity_full_patches(pm, P, n):
     """Meshes large enough that every patch of the operator is full (at P = 2 a
     wavefront takes 7 cells, which does not divide the 32 cells of a patch), on a
@@ -731,8 +733,8 @@ def test_apply_parity_random_small_meshes(pm):
 
 # every degree, on meshes that give at least two full patches per colour (patch shapes:
 # patches.hpp patch_shape) -- the coloured launches are the path the bench times
-@pytest.mark.parametrize("P,n", [(1, (8, 8, 32)), (2, (8, 8, 32)), (3, (4, 4, 32)), (4, (4, 4, 32)), (5, (4, 4, 16)),
-                                 (6, (4, 4, 8)), (7, (4, 4, 8)), (8, (2, 2, 16))])
+@pytest.mark.parametrize("P,n", [(1, (8, 8, 32)), (2, (8, 8, 32)), (3, (4, 4, 32)), (4, (4, 4, 32)), (5, (4, 4, 14)),
+                                 (6, (4, 4, 8)), (7, (4, 4, 12)), (8, (2, 2, 12))])
 def test_merged_and_coloured_launches_agree(pm, P, n):
     """The same operator built with the interior colours as separate launches (plain stores) and
     merged into one launch (atomics): same result, and both equal the oracle."""
