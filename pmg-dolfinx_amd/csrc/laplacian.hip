@@ -439,7 +439,11 @@ __device__ __forceinline__ double slice_load(double& v)
   else
     return v;
 }
+#ifdef PMG_UNPAIRED_MASK // experiment: bit P set = unpaired slice reads at degree P
+constexpr bool unpaired_slice_reads(int P) { return (PMG_UNPAIRED_MASK >> P) & 1; }
+#else
 constexpr bool unpaired_slice_reads(int P) { return P == 5 || P == 8; }
+#endif
 
 // minimum waves per SIMD the register allocation has to leave room for: two workgroups per CU up to
 // P = 4; the register-heavy degrees take what they need (profiles/kernel_resources_r02.md)
