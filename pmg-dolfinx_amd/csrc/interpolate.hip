@@ -9,6 +9,7 @@
 #include "patches.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 
 using namespace pmg;
@@ -843,6 +844,8 @@ extern "C" int pmg_interpolator_create_with_operator(
   const size_t per_wave = (size_t)ip->Nf + ndf * ndc * ndc + ndf * ndf * ndc;
   const size_t base = (size_t)ndf * ndc + cmax + v.max_m;
   int waves = 8;
+  if (const char* e = std::getenv("PMG_TRANSFER_WAVES")) // tuning: waves per patch (1 .. 16)
+    waves = std::max(1, std::min(16, std::atoi(e)));
   while (waves > 1 && 8 * (base + waves * per_wave) > 64 * 1024)
     --waves;
   ip->pwaves = waves;
