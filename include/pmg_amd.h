@@ -165,6 +165,16 @@ int pmg_window_alloc(size_t bytes, void** ptr, char* handle /* [PMG_WINDOW_HANDL
 int pmg_window_open(const char* handle, void** ptr);
 int pmg_window_close(void* ptr);
 int pmg_window_free(void* ptr);
+/* A communicator made of windows: the reductions and the set-up gathers of the ranks of one node without a transport
+ * library (no RCCL, no MPI): every rank allocates one window of PMG_COMM_WINDOW_BYTES with pmg_window_alloc, hands its
+ * handle to all ranks, maps theirs (pmg_window_open; windows[rank] is its own pointer) and creates the communicator.
+ * An all-reduce is two kernels on the caller's stream (stores into every rank's window + flags; wait + combine in rank
+ * order, so every rank gets the same bits), replays from a hipGraph, and costs no host work beyond the two launches.
+ * Layouts on such a communicator need halo windows for their exchange (pmg_layout_set_windows).  Every rank must issue
+ * the reductions of the communicator in the same order, one stream at a time.  The windows must outlive it. */
+#define PMG_COMM_WINDOW_MAX_RANKS 16
+#define PMG_COMM_WINDOW_BYTES (8 * (2 * PMG_COMM_WINDOW_MAX_RANKS + 8 + 2 * PMG_COMM_WINDOW_MAX_RANKS * 4096))
+int pmg_comm_create_windows(pmg_comm* out, int rank, int nranks, void* const* windows /* [nranks] */);
 int pmg_layout_window_describe(int32_t n_neighbors, const int32_t* send_counts, const int32_t* recv_counts,
                                int64_t* window_doubles, int64_t* fwd_offsets, int64_t* rev_offsets);
 int pmg_layout_set_windows(pmg_layout l, int32_t n_neighbors, const int32_t* send_counts, const int32_t* recv_counts,

@@ -13,5 +13,5 @@ from .laplacian import MatFreeLaplacian, set_merge_threshold  # noqa: F401
 from .mesh import BoxPartition, default_proc_dims  # noqa: F401
 from .pmg import MultigridPreconditioner  # noqa: F401
 from .problem import PoissonHierarchy, make_layout  # noqa: F401
-from .vector import (Layout, RcclComm, TorchComm, Vector, axpy, copy, inner_product, norm, pointwise_mult, scale,  # noqa: F401
+from .vector import (Layout, RcclComm, TorchComm, Vector, WindowComm, axpy, copy, inner_product, norm, pointwise_mult, scale,  # noqa: F401
                      squared_norm)

@@ -47,6 +47,7 @@ _SIGS = {
     "pmg_comm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p]),
     "pmg_comm_destroy": (C.c_int, [vp]),
     "pmg_comm_capture_overlaps": (C.c_int, []),
+    "pmg_comm_create_windows": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp)]),
     "pmg_comm_allgather": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "pmg_comm_rank": (C.c_int, [vp]),
     "pmg_comm_size": (C.c_int, [vp]),

@@ -91,15 +91,6 @@ int load_rccl()
   } while (0)
 } // namespace
 
-struct pmg_comm_s
-{
-  ncclComm_t comm = nullptr;
-  int rank = 0, nranks = 1;
-  hipStream_t stream = nullptr; // every RCCL call of this communicator is issued here, in program order
-  hipEvent_t ev_in = nullptr, ev_out = nullptr; // reductions: compute stream -> comm stream -> compute stream
-  bool reduced_eagerly = false; // an all-reduce has been issued outside a capture (see comm_capture_ready)
-};
-
 static_assert(sizeof(ncclUniqueId) == PMG_COMM_ID_BYTES, "pmg_comm id size");
 
 extern "C" int pmg_comm_unique_id(char* id)
@@ -136,6 +127,7 @@ extern "C" int pmg_comm_destroy(pmg_comm c)
     return PMG_OK;
   if (c->stream)
     (void)hipStreamSynchronize(c->stream);
+  wcomm_destroy(c);
   if (c->comm && g_rccl.CommDestroy)
     (void)g_rccl.CommDestroy(c->comm);
   if (c->ev_in)
@@ -153,6 +145,8 @@ extern "C" int pmg_comm_destroy(pmg_comm c)
 extern "C" int pmg_comm_allgather(pmg_comm c, const void* send, size_t bytes, void* recv)
 {
   PMG_REQUIRE(c && send && recv && bytes > 0, "pmg_comm_allgather: bad argument");
+  if (c->wcomm)
+    return wcomm_allgather(c, send, bytes, recv);
   char *d_in = nullptr, *d_out = nullptr;
   PMG_HIP(hipMalloc(&d_in, bytes));
   hipError_t e = hipMalloc(&d_out, bytes * (size_t)c->nranks);
@@ -270,6 +264,8 @@ int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s)
   pmg_comm c = l->comm;
   if (l->nb_rank.empty()) // no partner: nothing to post (point-to-point groups are not collectives)
     return PMG_OK;
+  PMG_REQUIRE(c->comm, "this communicator is made of windows and moves no halo by itself: attach halo windows to the "
+                       "layout (pmg_layout_set_windows)");
   // While `s` is being captured into a graph the replayed cycle costs the host one hipGraphLaunch instead of
   // ~115 us per exchange.  On a runtime whose capture can take it (capture_fork_supported) the communicator's
   // stream is forked into the capture exactly as in the eager path -- event on `s`, wait on the communicator's stream,
@@ -319,7 +315,7 @@ int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s)
 // sequence, which is the same on all ranks of a partitioned problem.
 bool comm_capture_ready(pmg_layout l, bool with_allreduce)
 {
-  if (!l->comm)
+  if (!l->comm || l->comm->wcomm) // (a communicator of windows: plain kernels, nothing to warm up)
     return true;
   if (!l->win && !l->nb_rank.empty() && !l->exchanged_eagerly) // halo windows are plain kernels: nothing to warm up
     return false;
@@ -338,6 +334,8 @@ int comm_exchange_end(pmg_layout l, hipStream_t s)
 int comm_allreduce(pmg_layout l, double* d_values, int n, bool max, hipStream_t s)
 {
   pmg_comm c = l->comm;
+  if (c->wcomm)
+    return wcomm_allreduce(c, d_values, n, max, s);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   PMG_HIP(hipStreamIsCapturing(s, &cap));
   if (cap == hipStreamCaptureStatusActive) // inside a graph capture: on `s` itself (see comm_exchange_begin)

@@ -80,8 +80,22 @@ struct HandleGuard
   }
 };
 
-struct pmg_comm_s;
+struct ncclComm;
 struct pmg_window_s;
+struct pmg_window_comm_s;
+
+// One process's communicator: RCCL (comm.hip) or, without any transport library, a window of device memory that
+// every rank has mapped (window.hip: reductions and set-up gathers as direct stores + flags; the halo of its layouts
+// then has to be halo windows as well).
+struct pmg_comm_s
+{
+  ncclComm* comm = nullptr;
+  pmg_window_comm_s* wcomm = nullptr;
+  int rank = 0, nranks = 1;
+  hipStream_t stream = nullptr; // every RCCL call of this communicator is issued here, in program order
+  hipEvent_t ev_in = nullptr, ev_out = nullptr; // reductions: compute stream -> comm stream -> compute stream
+  bool reduced_eagerly = false; // an all-reduce has been issued outside a capture (see comm_capture_ready)
+};
 
 struct pmg_layout_s
 {
@@ -133,6 +147,10 @@ bool comm_capture_ready(pmg_layout l, bool with_allreduce);
 int window_exchange_begin(pmg_layout l, bool reverse, const double* x, hipStream_t s);
 int window_exchange_end(pmg_layout l, bool reverse, double* x, hipStream_t s);
 void window_destroy(pmg_layout l);
+// ... and the reductions / set-up gathers of a communicator made of windows
+int wcomm_allreduce(pmg_comm c, double* d_values, int n, bool max, hipStream_t s);
+int wcomm_allgather(pmg_comm c, const void* send, size_t bytes, void* recv);
+void wcomm_destroy(pmg_comm c);
 
 // Profiling ranges (roctx, bound at run time; no-ops when libroctx64 is absent).  The reference
 // annotates each CG iteration (src/amd_gpu.hpp:236-252, src/cg.hpp:174,219); here every phase of

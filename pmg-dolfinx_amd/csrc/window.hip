@@ -461,3 +461,231 @@ extern "C" int pmg_layout_set_windows(pmg_layout l, int32_t n_neighbors, const i
   PMG_TRY(upload(pos, &w->recv_pos));
   return PMG_OK;
 }
+
+// ==================================================================================================
+// A communicator made of windows: the reductions (and the set-up gathers) without a transport library.
+//
+// Every rank owns one window of PMG_COMM_WINDOW_BYTES which all ranks map; an exchange of up to
+// WC_CHUNK doubles per rank is two kernels on the caller's stream, as for the halo:
+//   put : stores my values into slot [number & 1][my rank] of EVERY rank's window (my own included), one system-scope
+//         fence per workgroup, and the last workgroup raises arrived[slot][my rank] = number at every rank;
+//   get : waits for arrived[slot][r] >= number from all ranks r, then combines the R contributions in rank order
+//         (sum or maximum: the same bits on every rank) or lays them side by side (gather).
+// The exchange number lives on the device, so a captured all-reduce replays correctly.  Two slots suffice without
+// acknowledgements: a rank writes exchange n + 2 only after its get of n + 1 returned, i.e. after every rank had put
+// n + 1, which each of them does only after its own get of n -- provided a rank issues its puts and gets in one order
+// (one stream at a time), which is also what makes the ranks agree on the numbering.
+// Longer vectors (the replicated coarse solve sums whole level vectors) go chunk by chunk.
+namespace
+{
+constexpr int WC_MAXR = PMG_COMM_WINDOW_MAX_RANKS;
+constexpr int WC_CHUNK = 4096; // doubles per rank and exchange
+struct CommWindow              // the layout of a rank's window
+{
+  uint64_t arrived[2][WC_MAXR];
+  uint64_t sent, got, put_done, get_done; // owner only
+  uint64_t pad[4];
+  double values[2][WC_MAXR][WC_CHUNK];
+};
+static_assert(sizeof(CommWindow) == PMG_COMM_WINDOW_BYTES, "communicator window size");
+
+struct WCommDev
+{
+  int rank = 0, nranks = 1;
+  CommWindow* win[WC_MAXR]; // win[rank] is mine
+  int* err = nullptr;
+  long long timeout_ticks = 0;
+};
+
+__global__ void wcomm_put_kernel(const WCommDev* __restrict__ wp, int m, const double* __restrict__ src)
+{
+  const WCommDev& w = *wp;
+  CommWindow* mine = w.win[w.rank];
+  const uint64_t n = load_dev(&mine->sent) + 1;
+  const int slot = (int)(n & 1);
+  const long long total = (long long)w.nranks * m;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+  {
+    const int r = (int)(i / m), j = (int)(i - (long long)r * m);
+    w.win[r]->values[slot][w.rank][j] = src[j];
+  }
+  __syncthreads();
+  __shared__ int s_last;
+  if (threadIdx.x == 0)
+  {
+    __threadfence_system();
+    const unsigned long long prev = atomicAdd((unsigned long long*)&mine->put_done, 1ull);
+    s_last = prev == (unsigned long long)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x < 64)
+  {
+    __threadfence_system();
+    if ((int)threadIdx.x < w.nranks)
+      store_sys(&w.win[threadIdx.x]->arrived[slot][w.rank], n);
+    if (threadIdx.x == 0)
+    {
+      __hip_atomic_store(&mine->put_done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&mine->sent, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// MODE 0: sum, 1: maximum (dst[j] over the ranks, in rank order), 2: gather (dst[r * m + j])
+template <int MODE>
+__global__ void wcomm_get_kernel(const WCommDev* __restrict__ wp, int m, double* __restrict__ dst)
+{
+  const WCommDev& w = *wp;
+  CommWindow* mine = w.win[w.rank];
+  __shared__ uint64_t s_n;
+  if (threadIdx.x < 64)
+  {
+    const uint64_t n = load_dev(&mine->got) + 1;
+    if ((int)threadIdx.x < w.nranks)
+      if (!wait_flag(&mine->arrived[n & 1][threadIdx.x], n, w.timeout_ticks))
+        *w.err = PMG_WINDOW_ERR_NO_ARRIVAL;
+    if (threadIdx.x == 0)
+      s_n = n;
+  }
+  __syncthreads();
+  const uint64_t n = s_n;
+  const int slot = (int)(n & 1);
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x)
+  {
+    double acc = 0.0;
+    for (int r = 0; r < w.nranks; ++r)
+    {
+      const double v = __hip_atomic_load(&mine->values[slot][r][j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (MODE == 2)
+        dst[(size_t)r * m + j] = v;
+      else if (MODE == 1)
+        acc = r == 0 ? v : fmax(acc, v);
+      else
+        acc = r == 0 ? v : acc + v;
+    }
+    if (MODE != 2)
+      dst[j] = acc;
+  }
+  __syncthreads();
+  __shared__ int s_last;
+  if (threadIdx.x == 0)
+  {
+    const unsigned long long prev = atomicAdd((unsigned long long*)&mine->get_done, 1ull);
+    s_last = prev == (unsigned long long)gridDim.x - 1;
+    if (s_last)
+    {
+      __hip_atomic_store(&mine->get_done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&mine->got, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+int wc_blocks(long long items)
+{
+  const long long b = (items + 4 * 256 - 1) / (4 * 256);
+  return (int)(b < 1 ? 1 : (b > 64 ? 64 : b));
+}
+} // namespace
+
+struct pmg_window_comm_s
+{
+  WCommDev host;
+  WCommDev* dev = nullptr;
+  int* err = nullptr;          // pinned
+  double* stage = nullptr;     // device: the gather's staging, WC_CHUNK * (1 + WC_MAXR) doubles
+};
+
+namespace pmg
+{
+void wcomm_destroy(pmg_comm c)
+{
+  pmg_window_comm_s* w = c->wcomm;
+  if (!w)
+    return;
+  (void)hipFree(w->dev);
+  (void)hipFree(w->stage);
+  (void)hipHostFree(w->err);
+  delete w;
+  c->wcomm = nullptr;
+}
+
+static int wcomm_check(pmg_window_comm_s* w)
+{
+  if (*(volatile int*)w->err == 0)
+    return PMG_OK;
+  return fail(PMG_ERR_HIP, "communicator windows: a rank's contribution did not arrive within the time limit "
+                           "(PMG_WINDOW_TIMEOUT_MS)");
+}
+
+int wcomm_allreduce(pmg_comm c, double* d_values, int n, bool max, hipStream_t s)
+{
+  pmg_window_comm_s* w = c->wcomm;
+  PMG_TRY(wcomm_check(w));
+  for (int o = 0; o < n; o += WC_CHUNK)
+  {
+    const int m = n - o < WC_CHUNK ? n - o : WC_CHUNK;
+    wcomm_put_kernel<<<wc_blocks((long long)c->nranks * m), 256, 0, s>>>(w->dev, m, d_values + o);
+    if (max)
+      wcomm_get_kernel<1><<<wc_blocks(m), 256, 0, s>>>(w->dev, m, d_values + o);
+    else
+      wcomm_get_kernel<0><<<wc_blocks(m), 256, 0, s>>>(w->dev, m, d_values + o);
+  }
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+// blocking, set-up only: on the null stream, so it is ordered against everything the caller has in flight
+int wcomm_allgather(pmg_comm c, const void* send, size_t bytes, void* recv)
+{
+  pmg_window_comm_s* w = c->wcomm;
+  PMG_TRY(wcomm_check(w));
+  const size_t chunk_bytes = sizeof(double) * WC_CHUNK;
+  std::vector<double> host((size_t)WC_CHUNK * (size_t)c->nranks);
+  for (size_t o = 0; o < bytes; o += chunk_bytes)
+  {
+    const size_t b = bytes - o < chunk_bytes ? bytes - o : chunk_bytes;
+    const int m = (int)((b + 7) / 8);
+    std::vector<double> in((size_t)m, 0.0);
+    std::memcpy(in.data(), static_cast<const char*>(send) + o, b);
+    PMG_HIP(hipMemcpy(w->stage, in.data(), sizeof(double) * m, hipMemcpyHostToDevice));
+    wcomm_put_kernel<<<wc_blocks((long long)c->nranks * m), 256, 0, nullptr>>>(w->dev, m, w->stage);
+    wcomm_get_kernel<2><<<wc_blocks(m), 256, 0, nullptr>>>(w->dev, m, w->stage + WC_CHUNK);
+    PMG_HIP(hipGetLastError());
+    PMG_HIP(hipMemcpy(host.data(), w->stage + WC_CHUNK, sizeof(double) * m * (size_t)c->nranks, hipMemcpyDeviceToHost));
+    PMG_TRY(wcomm_check(w));
+    for (int r = 0; r < c->nranks; ++r)
+      std::memcpy(static_cast<char*>(recv) + (size_t)r * bytes + o, host.data() + (size_t)r * m, b);
+  }
+  return PMG_OK;
+}
+} // namespace pmg
+
+extern "C" int pmg_comm_create_windows(pmg_comm* out, int rank, int nranks, void* const* windows)
+{
+  PMG_REQUIRE(out && windows && nranks >= 1 && nranks <= WC_MAXR && rank >= 0 && rank < nranks,
+              "pmg_comm_create_windows: bad argument (at most %d ranks)", WC_MAXR);
+  for (int r = 0; r < nranks; ++r)
+    PMG_REQUIRE(windows[r], "pmg_comm_create_windows: rank %d has no window", r);
+  auto* c = new pmg_comm_s;
+  HandleGuard<pmg_comm> guard(c, pmg_comm_destroy);
+  c->rank = rank;
+  c->nranks = nranks;
+  auto* w = new pmg_window_comm_s;
+  c->wcomm = w;
+  w->host.rank = rank;
+  w->host.nranks = nranks;
+  for (int r = 0; r < nranks; ++r)
+    w->host.win[r] = static_cast<CommWindow*>(windows[r]);
+  long long ms = 5000;
+  if (const char* e = std::getenv("PMG_WINDOW_TIMEOUT_MS"))
+    ms = std::atoll(e) > 0 ? std::atoll(e) : ms;
+  w->host.timeout_ticks = ms * 100000ll;
+  PMG_HIP(hipHostMalloc(&w->err, sizeof(int), hipHostMallocMapped));
+  *w->err = 0;
+  w->host.err = w->err;
+  PMG_HIP(hipMalloc(&w->dev, sizeof(WCommDev)));
+  PMG_HIP(hipMemcpy(w->dev, &w->host, sizeof(WCommDev), hipMemcpyHostToDevice));
+  PMG_HIP(hipMalloc(&w->stage, sizeof(double) * WC_CHUNK * (1 + (size_t)WC_MAXR)));
+  *out = guard.release();
+  return PMG_OK;
+}

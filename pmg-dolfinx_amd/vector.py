@@ -179,6 +179,71 @@ class RcclComm:
             pass
 
 
+class WindowComm:
+    """The library's communicator WITHOUT a transport library (``pmg_comm_create_windows``): reductions
+    and halo as direct stores into windows of device memory the ranks of one node map from each other
+    (``hipIpc``), signalled by counters -- two kernels per exchange, no RCCL, no MPI, no host callback.
+    The interprocess handles travel once, at set-up, over ``gather`` (any callable returning every
+    rank's picklable object in rank order; :meth:`from_torch` uses a ``torch.distributed`` group)."""
+
+    halo = "windows"
+    distributed = True
+    WINDOW_BYTES = 8 * (2 * 16 + 8 + 2 * 16 * 4096)
+
+    def __init__(self, rank: int, size: int, gather, host=None):
+        import os
+
+        self.rank, self.world = int(rank), int(size)
+        self._gather, self._host = gather, host
+        self._window, handle = HaloWindows._alloc(self.WINDOW_BYTES)
+        everyone = gather({"handle": handle, "pid": os.getpid(), "pointer": self._window.value})
+        self._opened = []
+        ptrs = (vp * self.world)()
+        for r, info in enumerate(everyone):
+            if r == self.rank or info["pid"] == os.getpid():
+                ptrs[r] = info["pointer"]
+            else:
+                p = vp()
+                call("pmg_window_open", C.c_char_p(info["handle"]), C.byref(p))
+                self._opened.append(p)
+                ptrs[r] = p.value
+        h = vp()
+        call("pmg_comm_create_windows", C.byref(h), self.rank, self.world, ptrs)
+        self.native = h
+        gather(True)  # every rank has mapped every window before anybody stores
+
+    @classmethod
+    def from_torch(cls, group=None):
+        host = TorchComm(group)
+        return cls(host.rank, host.world, host.gather_objects, host=host)
+
+    def size(self) -> int:
+        return int(_lib.lib().pmg_comm_size(self.native))
+
+    def gather_objects(self, obj):
+        return self._gather(obj)
+
+    def all_to_all_host(self, layout, send, recv_count):
+        if self._host is None:
+            raise RuntimeError("WindowComm without a host-side bootstrap group cannot move host arrays")
+        return self._host.all_to_all_host(layout, send, recv_count)
+
+    def __del__(self):
+        try:
+            lib = _lib.lib()
+            if getattr(self, "native", None) is not None:
+                lib.pmg_comm_destroy(self.native)
+                self.native = None
+            for p in getattr(self, "_opened", []):
+                lib.pmg_window_close(p)
+            self._opened = []
+            if getattr(self, "_window", None) is not None:
+                lib.pmg_window_free(self._window)
+                self._window = None
+        except Exception:
+            pass
+
+
 class Layout:
     """Sizes + halo plan of one function space on this rank.
 

@@ -226,9 +226,11 @@ def _worker_body(rank, world, port, n, dims, orders, halo="exchange"):
         import pmg_dolfinx_amd as pm
 
         torch.cuda.set_device(0)
-        comm = pm.TorchComm(halo="windows") if halo == "windows" else None
+        comm = {"windows": lambda: pm.TorchComm(halo="windows"),       # halo windows, reductions on the gloo callbacks
+                "window-comm": lambda: pm.WindowComm.from_torch(),     # halo AND reductions through windows
+                "exchange": lambda: None}[halo]()
         out = _rank_checks(pm, rank, world, n, dims, orders, comm=comm)
-        if halo == "windows":
+        if halo != "exchange":
             # the same cycles replayed as a hipGraph: no host in the loop, so the ranks drift apart as far as the
             # protocol lets them (two exchanges) -- the exchange numbers kept on the device and the "consumed" counters
             # are what keeps the replays correct
@@ -272,12 +274,15 @@ def test_ranks_share_one_gpu(dims, n, built):
     _assert_rank_results(_run_ranks(_worker, world, (n, dims, orders)))
 
 
+@pytest.mark.parametrize("route", ["windows", "window-comm"])
 @pytest.mark.parametrize("dims,n", [((1, 1, 2), (3, 4, 8)), ((1, 2, 2), (3, 4, 6))])
-def test_ranks_share_one_gpu_through_halo_windows(dims, n, built):
+def test_ranks_share_one_gpu_through_halo_windows(dims, n, route, built):
     """The same checks with the halo moved by the library's windows: every rank (a process) stores its packed
     values straight into its neighbours' interprocess-mapped windows and waits on their flags -- the whole protocol of
     window.hip between real processes (two and four: the box admits six on its GPU, the test runner included), with the one GPU standing in for the
-    peers' GPUs (the reductions stay on the gloo callbacks).  Not run with the ranks as threads of one process: eight
+    peers' GPUs.  route "windows": the reductions stay on the gloo callbacks; "window-comm": the library's communicator
+    made of windows -- no transport library at all, every reduction (the dot products of CG, the sums of whole level
+    vectors in the replicated coarse solve: chunked) two kernels of direct stores and flags.  Not run with the ranks as threads of one process: eight
     streams share the process's four hardware queues, and a kernel waiting for a flag at the head of a queue would
     hold back the very kernel that raises it."""
     import torch
@@ -286,7 +291,7 @@ def test_ranks_share_one_gpu_through_halo_windows(dims, n, built):
         pytest.skip("no GPU")
     orders = (1, 2, 4) if dims[0] * dims[1] * dims[2] == 2 else (1, 2)
     world = dims[0] * dims[1] * dims[2]
-    res = _run_ranks(_worker, world, (n, dims, orders, "windows"))
+    res = _run_ranks(_worker, world, (n, dims, orders, route))
     _assert_rank_results(res)
     for out in res:
         assert out["graph_replays"] >= 7 and out["graph_vs_eager"] < 1e-12, (out["graph_replays"], out["graph_vs_eager"])
