@@ -16,6 +16,8 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <type_traits>
+#include <vector>
 
 namespace examples
 {
@@ -25,6 +27,7 @@ struct RankOptions
   std::array<int, 3> ranks = {1, 1, 1};
   bool native_comm = false; // one rank through the RCCL communicator anyway
   bool windows = false;     // --halo windows: the halo as stores into the neighbours' windows, RCCL for the reductions
+  bool window_comm = false; // --comm windows: no RCCL at all -- reductions and halo through windows
   pmg_amd::Halo halo() const { return windows ? pmg_amd::Halo::windows : pmg_amd::Halo::exchange; }
   std::string id_file = "/tmp/pmg_amd_comm_id";
   int size() const { return ranks[0] * ranks[1] * ranks[2]; }
@@ -60,12 +63,56 @@ inline void select_device(const RankOptions& o)
   pmg_amd::hip_check(hipSetDevice(env_int({"LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK"}, o.rank) % ndev), "hipSetDevice");
 }
 
-/// The library's RCCL communicator over all ranks (null on one rank without --native-comm).
+/// Every rank's fixed-size record in rank order, through files next to the id file (rank r writes <id-file>.w<r>).
+template <typename R>
+std::vector<R> file_allgather(const RankOptions& o, const R& mine)
+{
+  static_assert(std::is_trivially_copyable_v<R>);
+  const auto started = std::filesystem::file_time_type::clock::now() - std::chrono::seconds(30);
+  auto name = [&](int r) { return o.id_file + ".w" + std::to_string(r); };
+  {
+    const std::string tmp = name(o.rank) + ".tmp";
+    {
+      std::ofstream f(tmp, std::ios::binary);
+      f.write(reinterpret_cast<const char*>(&mine), sizeof(R));
+    }
+    std::rename(tmp.c_str(), name(o.rank).c_str()); // atomic: readers never see a partial record
+  }
+  std::vector<R> all((std::size_t)o.size());
+  for (int r = 0; r < o.size(); ++r)
+    for (int tries = 0;; ++tries)
+    {
+      std::error_code ec;
+      const auto written = std::filesystem::last_write_time(name(r), ec);
+      if (!ec && written >= started)
+      {
+        std::ifstream f(name(r), std::ios::binary);
+        if (f && f.read(reinterpret_cast<char*>(&all[(std::size_t)r]), sizeof(R)))
+          break;
+      }
+      if (tries > 600)
+        throw std::runtime_error("timed out waiting for rank " + std::to_string(r) + "'s record in " + name(r));
+      std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+  return all;
+}
+
+/// The library's communicator over all ranks (null on one rank without --native-comm): RCCL, or with --comm windows
+/// the communicator made of windows (no transport library; the ranks may then even share a GPU).
 inline std::shared_ptr<const pmg_amd::Communicator> bootstrap(const RankOptions& o)
 {
   const int size = o.size();
   if (size == 1 && !o.native_comm)
     return nullptr;
+  if (o.window_comm)
+  {
+    using WH = pmg_amd::Communicator::WindowHandle;
+    auto comm = std::make_shared<const pmg_amd::Communicator>(
+        o.rank, size, [&](const WH& mine) { return file_allgather<WH>(o, mine); });
+    (void)comm->allgather(o.rank); // every rank has read every record: the files can go
+    std::remove((o.id_file + ".w" + std::to_string(o.rank)).c_str());
+    return comm;
+  }
   std::array<char, PMG_COMM_ID_BYTES> id{};
   // A file left by an earlier run must not hand a stale id to this one: rank 0 removes it before it creates the
   // new id, and the other ranks accept only a file written after they started (minus a margin for launchers

@@ -371,6 +371,13 @@ int main(int argc, char** argv)
         o.rank = std::atoi(next());
       else if (!std::strcmp(argv[i], "--native-comm")) // one rank through the RCCL communicator anyway
         o.native_comm = true;
+      else if (!std::strcmp(argv[i], "--comm"))
+      {
+        const std::string how = next();
+        if (how != "windows" && how != "rccl")
+          throw std::runtime_error("--comm rccl | windows");
+        o.window_comm = how == "windows";
+      }
       else if (!std::strcmp(argv[i], "--halo"))
       {
         const std::string how = next();
@@ -389,6 +396,7 @@ int main(int argc, char** argv)
         std::cout << "usage: pmg [--n cells_per_direction | --ndofs N_per_rank] [--orders 1,2,4] [--smoother-its K]\n"
                      "           [--cycles C] [--pcg [--random-rhs]] [--amg | --amg-cycles N | --coarse-cg] [--graph]\n"
                      "           [--ranks px,py,pz [--rank r] [--id-file F]] [--native-comm] [--halo exchange|windows]\n"
+                     "           [--comm rccl|windows]\n"
                      "           [--output FILE]\n"
                      "           [--check-partition px,py,pz]\n";
         return !std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h") ? 0 : 2;

@@ -43,6 +43,7 @@
 
 #include <array>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <span>
@@ -138,9 +139,49 @@ public:
   {
     check(pmg_comm_create(&_c, rank, size, id.data()));
   }
+  /// What a rank publishes about its window for the communicator made of windows (pmg_comm_create_windows).
+  struct WindowHandle
+  {
+    char handle[PMG_WINDOW_HANDLE_BYTES] = {};
+    std::int32_t pid = 0;
+    void* pointer = nullptr; // meaningful inside process `pid` only
+  };
+  /// A communicator without a transport library: `allgather` hands this rank's WindowHandle to every rank and returns
+  /// all of them in rank order -- once, at set-up, by whatever means the caller has (files, MPI_Allgather, a socket).
+  Communicator(int rank, int size, const std::function<std::vector<WindowHandle>(const WindowHandle&)>& allgather)
+  {
+    WindowHandle mine;
+    check(pmg_window_alloc(PMG_COMM_WINDOW_BYTES, &_window, mine.handle));
+    mine.pid = (std::int32_t)getpid();
+    mine.pointer = _window;
+    const std::vector<WindowHandle> all = allgather(mine);
+    if ((int)all.size() != size)
+      throw std::runtime_error("Communicator: the window handles of all ranks are needed");
+    std::vector<void*> windows((std::size_t)size, nullptr);
+    for (int r = 0; r < size; ++r)
+    {
+      if (r == rank || all[(std::size_t)r].pid == mine.pid)
+        windows[(std::size_t)r] = all[(std::size_t)r].pointer;
+      else
+      {
+        check(pmg_window_open(all[(std::size_t)r].handle, &windows[(std::size_t)r]));
+        _opened.push_back(windows[(std::size_t)r]);
+      }
+    }
+    check(pmg_comm_create_windows(&_c, rank, size, windows.data()));
+    _windows = true;
+  }
   Communicator(const Communicator&) = delete;
   Communicator& operator=(const Communicator&) = delete;
-  ~Communicator() { pmg_comm_destroy(_c); }
+  ~Communicator()
+  {
+    pmg_comm_destroy(_c);
+    for (void* p : _opened)
+      pmg_window_close(p);
+    pmg_window_free(_window);
+  }
+  /// true: made of windows -- its IndexMaps need Halo::windows
+  bool windows() const { return _windows; }
   int rank() const { return pmg_comm_rank(_c); }
   int size() const { return pmg_comm_size(_c); }
   pmg_comm handle() const { return _c; }
@@ -156,6 +197,9 @@ public:
 
 private:
   pmg_comm _c = nullptr;
+  void* _window = nullptr;
+  std::vector<void*> _opened;
+  bool _windows = false;
 };
 
 /// How the halo of an IndexMap with a communicator travels: grouped ncclSend / ncclRecv, or direct stores into the
@@ -200,7 +244,7 @@ public:
     _comm = std::move(comm);
     check(pmg_layout_set_comm(_layout, _comm->handle(), (std::int32_t)neighbors.size(), neighbors.data(),
                               send_counts.data(), recv_counts.data()));
-    if (halo == Halo::windows)
+    if (halo == Halo::windows || _comm->windows())
       attach_windows(neighbors, send_counts, recv_counts);
   }
   IndexMap(const IndexMap&) = delete;

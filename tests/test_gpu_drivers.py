@@ -230,3 +230,30 @@ def test_bench_refuses_more_gpus_than_the_box_has():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 2 and r.stdout.strip() == ""
     assert f"--gpus {n}" in r.stderr and "refusing" in r.stderr
+
+
+@pytest.mark.parametrize("dims", ["1,1,2", "1,2,2"])
+def test_pmg_driver_ranks_share_the_gpu_through_the_window_communicator(built, dims):
+    """examples/pmg/run_ranks.sh with --comm windows: the C++ driver as 2 and 4 PROCESSES, one brick each, on the one
+    GPU of the box (RCCL refuses two ranks on a device; the communicator made of windows does not care): the file
+    bootstrap of the window handles, halo windows, the all-reduces of CG and of the replicated AMG.  Same global
+    problem as the single-process run, so the same residuals cycle by cycle, and hipGraph replays on top."""
+    script = os.path.join(ROOT, "examples", "pmg", "run_ranks.sh")
+    args = ["--n", "8", "--orders", "1,2,4", "--smoother-its", "3", "--cycles", "4"]
+
+    def ranks(*extra):
+        r = subprocess.run(["bash", script, dims, *args, "--comm", "windows", *extra], capture_output=True, text=True,
+                           timeout=300, env={**os.environ, "PMG_WINDOW_TIMEOUT_MS": "20000"})
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r.stdout
+
+    for extra in ([], ["--amg-cycles", "2"]):
+        one = grab(r"Cycle \d+: residual norm = (\S+)", run("pmg_main", *args, *extra))
+        many = grab(r"Cycle \d+: residual norm = (\S+)", ranks(*extra))
+        assert len(one) == len(many) == 4
+        tol = 1e-9 if not extra else 1e-5  # the AMG hierarchy of the replicated solve orders its sums differently
+        assert all(abs(a - b) < tol * one[0] for a, b in zip(one, many)), (one, many)
+    out = ranks("--graph", "--pcg")
+    assert "(hipGraph replays)" in out
+    m = re.search(r"PCG with V-cycle preconditioner: (\d+) iterations, \|b - A x\| / \|b\| = ([0-9.e+-]+)", out)
+    assert m and float(m.group(2)) < 1e-6
