@@ -101,6 +101,15 @@ def parse_args(argv=None):
                          "serves the reductions only).  The windows are validated between processes sharing one GPU "
                          "(tests/test_gpu_distributed.py), not yet between GPUs -- hence opt-in; either way the first "
                          "thing a multi-rank run does is check a forward scatter against the partition's own index map")
+    ap.add_argument("--comm", choices=["rccl", "windows"], default="rccl",
+                    help="N > 1: the library's communicator on RCCL (default) or made of windows (pmg_comm_create_windows: "
+                         "reductions AND halo as direct stores into IPC-mapped device memory, no transport library in "
+                         "the data path; validated between processes sharing one GPU, not yet between GPUs)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="REHEARSAL on a box with fewer GPUs than ranks: all --gpus N ranks run on GPU 0 (needs --comm "
+                         "windows; the launcher's group is gloo).  Exercises the whole multi-rank path with real "
+                         "inter-process exchanges; the line it prints says n_gpus = 1 and carries a `rehearsal` note -- "
+                         "it is not a multi-GPU measurement")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaled config-3 measurement")
     ap.add_argument("--graph-exchange", action="store_true",
                     help="N > 1 with the library's communicator: additionally time the cycles replayed as a hipGraph "
@@ -145,21 +154,46 @@ def visible_gpus() -> int:
 
 def self_launch(args) -> int:
     """`python bench.py --gpus N` without a launcher (the reference: `srun -n 8`, examples/pmg/submit.sh:29):
-    start the N ranks as CHILD processes of a process that has not touched the GPU
-    (`python -m torch.distributed.run`, one rank per GPU), hand their stdout (rank 0's JSON line) through
-    and return the launcher's exit code."""
+    start the N ranks as CHILD processes of a process that has not touched the GPU -- what
+    `python -m torch.distributed.run --nproc-per-node N` would do (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT in the environment, one rank per GPU), without handing the script's own options to that launcher's
+    parser (which reads `--n 32` as an abbreviation of its own options) -- hand rank 0's stdout (the JSON line)
+    through and return the first non-zero exit code; a rank that fails takes the others down with it."""
     import subprocess
 
     have = visible_gpus()
+    if args.share_gpu and have >= 1:
+        have = args.gpus  # all ranks on GPU 0: a rehearsal, labelled as such in the line
     if have < args.gpus:
         raise LaunchError(f"--gpus {args.gpus} asked for, {have} GPU(s) visible: refusing to run "
                           f"(a {have or 1}-rank measurement must not be labelled {args.gpus} GPUs)")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    log("bench.py: no launcher in the environment, starting the ranks: " + " ".join(cmd))
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    port = free_port()
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"bench.py: no launcher in the environment, starting {args.gpus} ranks (127.0.0.1:{port}): " + " ".join(cmd))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd, env=env))
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        failed = [p.returncode for p in procs if p.returncode not in (None, 0)]
+        if failed:
+            rc = failed[0]
+            for p in procs:  # exactly the processes started above
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    for p in procs:
+        try:
+            p.wait(timeout=60)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    return rc or next((p.returncode for p in procs if p.returncode), 0)
 
 
 def main():
@@ -187,6 +221,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus
+    if args.share_gpu:
+        if args.comm != "windows":
+            raise LaunchError("--share-gpu needs --comm windows (RCCL refuses two ranks on one device)")
+        local_rank = 0
     if visible_gpus() <= local_rank:
         raise LaunchError(f"rank {rank}: local rank {local_rank} has no GPU ({visible_gpus()} visible); bench.py needs "
                           f"one GPU per rank (there is no CPU fallback of the product path)")
@@ -200,7 +238,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:  # only the one-rank rehearsal gets here without a launcher
             os.environ["MASTER_PORT"] = str(free_port())
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:  # control plane only (barriers, max over ranks): the data path is the library's windows
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ctl = "cpu" if args.share_gpu else "cuda"  # where the launcher's group reduces the bench's own scalars
     if rank == 0:
         ge.build()
     if multi:
@@ -215,11 +257,14 @@ def main():
     comm, comm_note = None, None
     if multi and args.exchange == "native":
         try:
-            comm = pm.RcclComm.from_torch(device=torch.device("cuda", local_rank), halo=args.halo)
+            if args.comm == "windows":
+                comm = pm.WindowComm.from_torch()
+            else:
+                comm = pm.RcclComm.from_torch(device=torch.device("cuda", local_rank), halo=args.halo)
         except Exception as e:  # e.g. no librccl to bind: every rank fails alike; the callback route still is RCCL
             comm_note = f"native communicator unavailable ({type(e).__name__}: {e}); torch.distributed callbacks"
             log(f"[rank {rank}] {comm_note}")
-        ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+        ok = torch.tensor([1 if comm is not None else 0], device=ctl)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             comm = None  # all ranks on the same route
@@ -245,7 +290,7 @@ def main():
             v.data.copy_(torch.from_numpy(loc))
             v.scatter_fwd()
             good = torch.tensor([1 if np.array_equal(v.data_copy(), np.asarray(lv.local_to_global, dtype=np.float64))
-                                 else 0], device="cuda")
+                                 else 0], device=ctl)
             dist.all_reduce(good, op=dist.ReduceOp.MIN)
             if int(good.item()) == 0:
                 raise LaunchError(f"[rank {rank}] the halo exchange ({args.halo}) does not reproduce the index map")
@@ -271,7 +316,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t_start
     if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
@@ -340,11 +385,23 @@ def main():
                 "cells_per_launch": ncells_launch,
                 "launches_per_apply": nlaunch, "apply_ms": round(kernel_ms * nlaunch, 5)}
 
+    if not multi:
+        exchange_note = "none (single rank)"
+    elif comm is None:
+        exchange_note = comm_note or "torch.distributed callbacks"
+    elif args.comm == "windows":
+        exchange_note = ("library communicator made of windows: halo and reductions as direct stores into IPC-mapped "
+                         "device memory, no transport library")
+    elif args.halo == "windows":
+        exchange_note = ("library halo windows (direct stores into the neighbours' IPC-mapped memory), RCCL device "
+                         "all-reduce")
+    else:
+        exchange_note = "library RCCL communicator (grouped send/recv, device all-reduce)"
     out = {
         "metric": "DoFs/sec per p-MG V-cycle (Poisson, hex, p=4)",
         "value": value,
         "unit": "DoF/s",
-        "n_gpus": world,
+        "n_gpus": 1 if args.share_gpu else world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
@@ -362,10 +419,7 @@ def main():
             "levels": list(reversed(orders)),
             "cheb_iterations": args.cheb,
             "partition": "x".join(str(d) for d in dims) + " bricks, 1 ghost-cell layer",
-            "exchange": (("library halo windows (direct stores into the neighbours' IPC-mapped memory), RCCL device "
-                          "all-reduce" if args.halo == "windows" else
-                          "library RCCL communicator (grouped send/recv, device all-reduce)") if comm is not None
-                         else (comm_note or "torch.distributed callbacks")) if multi else "none (single rank)",
+            "exchange": exchange_note,
             "stiffness_launches_per_cycle": {f"p{p}": c for p, c in zip(orders, counts)},
             # ranks of the communicator the halo and the reductions really ran on (pmg_comm_size of the library's
             # RCCL communicator, or torch.distributed's RCCL group on the callback route); 1 = no communicator
@@ -376,6 +430,11 @@ def main():
         },
         "roofline": roofline,
     }
+    if args.share_gpu:
+        out["rehearsal"] = (f"{world} ranks SHARE ONE GPU (--share-gpu): a rehearsal of the multi-rank path with real "
+                            "inter-process exchanges, not a multi-GPU measurement; `value` is the aggregate of the "
+                            "ranks time-slicing that GPU")
+        out["ranks"] = world
     if graph_ms is not None:
         out["graph_replay"] = {"ms_per_step": graph_ms, "value": fine_dofs_global / (graph_ms * 1e-3), "unit": "DoF/s",
                                "note": "the same cycle replayed with one hipGraphLaunch per cycle"
@@ -390,7 +449,7 @@ def main():
         sync_all()
         t = time.perf_counter() - t
         if multi:
-            tt = torch.tensor([t], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([t], dtype=torch.float64, device=ctl)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t = float(tt.item())
         return t
@@ -566,7 +625,7 @@ def main():
             sync_all()
             ta = time.perf_counter() - ta
             if world > 1:
-                tt = torch.tensor([ta], dtype=torch.float64, device="cuda")
+                tt = torch.tensor([ta], dtype=torch.float64, device=ctl)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 ta = float(tt.item())
             op.time_kernel(u, y, 3)

@@ -49,29 +49,41 @@ def test_world_size_mismatch_is_an_error():
 
 
 def test_self_launch_starts_the_ranks_as_children(monkeypatch):
-    """With enough devices and no launcher in the environment, `--gpus N` becomes ONE child process:
-    `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` on a free local port;
-    the parent never initialises a GPU and returns the launcher's exit code."""
+    """With enough devices and no launcher in the environment, `--gpus N` becomes N child processes
+    `python bench.py <same arguments>` with the launcher's environment (RANK, LOCAL_RANK, WORLD_SIZE, rendezvous on
+    127.0.0.1 and a free port); the parent never initialises a GPU and returns the first non-zero exit code."""
     b = _bench_module()
-    seen = {}
+    started = []
 
-    def fake_call(cmd, env=None):
-        seen["cmd"], seen["env"] = cmd, env
-        return 7
+    class FakeProc:
+        def __init__(self, cmd, env=None):
+            self.cmd, self.env = cmd, env
+            self.returncode = 7 if env["RANK"] == "2" else 0
+            started.append(self)
+
+        def poll(self):
+            return self.returncode
+
+        def wait(self, timeout=None):
+            return self.returncode
+
+        def terminate(self):
+            pass
 
     monkeypatch.setattr(b, "visible_gpus", lambda: 4)
-    monkeypatch.setattr(subprocess, "call", fake_call)
-    monkeypatch.setattr(sys, "argv", [BENCH, "--gpus", "4", "--steps", "2"])
-    args = b.parse_args(["--gpus", "4", "--steps", "2"])
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", [BENCH, "--gpus", "4", "--steps", "2", "--n", "32"])
+    args = b.parse_args(["--gpus", "4", "--steps", "2", "--n", "32"])
     assert b.self_launch(args) == 7
-    cmd = seen["cmd"]
-    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
-    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
-    port = int(cmd[cmd.index("--master-port") + 1])
-    assert 1024 < port < 65536
-    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and os.path.samefile(cmd[-5], BENCH)
-    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    assert len(started) == 4
+    ports = set()
+    for r, p in enumerate(started):
+        assert p.cmd[0] == sys.executable and os.path.samefile(p.cmd[1], BENCH)
+        assert p.cmd[2:] == ["--gpus", "4", "--steps", "2", "--n", "32"]  # the script's own options, untouched
+        assert (p.env["RANK"], p.env["LOCAL_RANK"], p.env["WORLD_SIZE"]) == (str(r), str(r), "4")
+        assert p.env["MASTER_ADDR"] == "127.0.0.1" and p.env.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+        ports.add(int(p.env["MASTER_PORT"]))
+    assert len(ports) == 1 and 1024 < ports.pop() < 65536
 
 
 def test_self_launch_refuses_when_devices_are_short(monkeypatch):
