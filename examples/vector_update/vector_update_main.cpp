@@ -47,7 +47,7 @@ void run(const Options& o)
   const examples::PartitionLevel lv = mesh.level(o.order, gll);
   std::shared_ptr<const common::IndexMap> map
       = comm ? std::make_shared<const common::IndexMap>(lv.size_local, lv.num_ghosts, lv.send_indices, lv.recv_indices,
-                                                         comm, lv.neighbors, lv.send_counts, lv.recv_counts)
+                                                         comm, lv.neighbors, lv.send_counts, lv.recv_counts, o.halo())
              : std::make_shared<const common::IndexMap>(lv.size_local, lv.num_ghosts);
   if (root)
   {
@@ -145,12 +145,16 @@ int main(int argc, char** argv)
         o.rank = std::atoi(next());
       else if (!std::strcmp(argv[i], "--native-comm"))
         o.native_comm = true;
+      else if (!std::strcmp(argv[i], "--halo")) // exchange | windows
+        o.windows = std::string(next()) == "windows";
+      else if (!std::strcmp(argv[i], "--comm")) // rccl | windows
+        o.window_comm = std::string(next()) == "windows";
       else if (!std::strcmp(argv[i], "--id-file"))
         o.id_file = next();
       else
       {
         std::cout << "usage: vector_update [--n cells_per_direction | --ndofs N_per_rank] [--degree P] [--iterations N]\n"
-                     "                     [--quiet] [--ranks px,py,pz [--rank r] [--id-file F]] [--native-comm]\n";
+                     "                     [--quiet] [--ranks px,py,pz [--rank r] [--id-file F]] [--native-comm] [--halo exchange|windows] [--comm rccl|windows]\n";
         return !std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h") ? 0 : 2;
       }
     }

@@ -257,3 +257,26 @@ def test_pmg_driver_ranks_share_the_gpu_through_the_window_communicator(built, d
     assert "(hipGraph replays)" in out
     m = re.search(r"PCG with V-cycle preconditioner: (\d+) iterations, \|b - A x\| / \|b\| = ([0-9.e+-]+)", out)
     assert m and float(m.group(2)) < 1e-6
+
+
+def test_cg_and_vector_update_drivers_as_ranks_sharing_the_gpu(built):
+    """cg_main and vector_update_main as two processes on the one GPU (--comm windows): the same global problem as the
+    single-process run -- same CG iteration count and eigenvalue estimates, same norms."""
+    script = os.path.join(ROOT, "examples", "pmg", "run_ranks.sh")
+
+    def ranks(exe, *args):
+        r = subprocess.run(["bash", script, "1,1,2", *map(str, args), "--comm", "windows"], capture_output=True,
+                           text=True, timeout=300,
+                           env={**os.environ, "PMG_MAIN": os.path.join(BIN, exe), "PMG_WINDOW_TIMEOUT_MS": "20000"})
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r.stdout
+
+    one, two = run("cg_main", "--n", 6, "--degree", 3), ranks("cg_main", "--n", 6, "--degree", 3)
+    assert grab(r"Number of iterations (\d+)", one) == grab(r"Number of iterations (\d+)", two)
+    e1 = re.findall(r"Computed eigs = \(([0-9.e+-]+), ([0-9.e+-]+)\)", one)[0]
+    e2 = re.findall(r"Computed eigs = \(([0-9.e+-]+), ([0-9.e+-]+)\)", two)[0]
+    assert all(abs(float(a) - float(b)) < 1e-9 * float(e1[1]) for a, b in zip(e1, e2))
+    (b1,), (b2,) = grab(r"Norm of b = (\S+)", one), grab(r"Norm of b = (\S+)", two)
+    assert abs(b1 - b2) < 1e-11 * b1
+    out = ranks("vector_update_main", "--n", 8, "--degree", 2, "--iterations", 20)
+    assert "Ghost check" in out and len(grab(r"Dot value: (\S+)", out)) == 20
