@@ -423,7 +423,9 @@ def main():
             "stiffness_launches_per_cycle": {f"p{p}": c for p, c in zip(orders, counts)},
             # ranks of the communicator the halo and the reductions really ran on (pmg_comm_size of the library's
             # RCCL communicator, or torch.distributed's RCCL group on the callback route); 1 = no communicator
-            "rccl_ranks": rccl_ranks,
+            "rccl_ranks": rccl_ranks if args.comm == "rccl" else 0,
+            # the same for whichever communicator carried the run (RCCL or the one made of windows)
+            "comm_ranks": rccl_ranks,
             # a halo exchange captured into a hipGraph keeps its overlap with the interior cells only on a HIP >= 7.2
             # runtime (profiles/rccl_capture_probe_r03.md); a Python process runs on PyTorch's bundled runtime
             "captured_exchange_overlaps": bool(pm._lib.lib().pmg_comm_capture_overlaps()) if multi else None,
