@@ -132,6 +132,8 @@ int pmg_comm_capture_overlaps(void);
 /* Set-up helper, blocking (where the reference's set-up calls MPI_Allgather): `bytes` bytes of host memory from every
  * rank, in rank order, into recv[size * bytes] on every rank. */
 int pmg_comm_allgather(pmg_comm comm, const void* send, size_t bytes, void* recv);
+/* values[0 .. n) (device memory) summed over the ranks in place, ordered on `stream` (MPI_Allreduce(MPI_IN_PLACE, SUM)). */
+int pmg_comm_allreduce_sum(pmg_comm comm, double* values, int n, pmg_stream stream);
 int pmg_comm_rank(pmg_comm comm);
 int pmg_comm_size(pmg_comm comm);
 int pmg_layout_set_comm(pmg_layout l, pmg_comm comm, int32_t n_neighbors, const int32_t* neighbor_ranks,
@@ -168,12 +170,14 @@ int pmg_window_free(void* ptr);
 /* A communicator made of windows: the reductions and the set-up gathers of the ranks of one node without a transport
  * library (no RCCL, no MPI): every rank allocates one window of PMG_COMM_WINDOW_BYTES with pmg_window_alloc, hands its
  * handle to all ranks, maps theirs (pmg_window_open; windows[rank] is its own pointer) and creates the communicator.
- * An all-reduce is two kernels on the caller's stream (stores into every rank's window + flags; wait + combine in rank
+ * An all-reduce of up to PMG_COMM_WINDOW_CHUNK doubles is two kernels on the caller's stream (stores into every rank's window + flags; wait + combine in rank
  * order, so every rank gets the same bits), replays from a hipGraph, and costs no host work beyond the two launches.
  * Layouts on such a communicator need halo windows for their exchange (pmg_layout_set_windows).  Every rank must issue
  * the reductions of the communicator in the same order, one stream at a time.  The windows must outlive it. */
 #define PMG_COMM_WINDOW_MAX_RANKS 16
-#define PMG_COMM_WINDOW_BYTES (8 * (2 * PMG_COMM_WINDOW_MAX_RANKS + 8 + 2 * PMG_COMM_WINDOW_MAX_RANKS * 4096))
+#define PMG_COMM_WINDOW_CHUNK 16384 /* doubles per rank and exchange; longer vectors go chunk by chunk */
+#define PMG_COMM_WINDOW_BYTES \
+  (8 * (2 * PMG_COMM_WINDOW_MAX_RANKS + 8 + 2 * PMG_COMM_WINDOW_MAX_RANKS * PMG_COMM_WINDOW_CHUNK))
 int pmg_comm_create_windows(pmg_comm* out, int rank, int nranks, void* const* windows /* [nranks] */);
 int pmg_layout_window_describe(int32_t n_neighbors, const int32_t* send_counts, const int32_t* recv_counts,
                                int64_t* window_doubles, int64_t* fwd_offsets, int64_t* rev_offsets);

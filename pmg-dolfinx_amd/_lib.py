@@ -49,6 +49,7 @@ _SIGS = {
     "pmg_comm_capture_overlaps": (C.c_int, []),
     "pmg_comm_create_windows": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(vp)]),
     "pmg_comm_allgather": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "pmg_comm_allreduce_sum": (C.c_int, [vp, vp, C.c_int, vp]),
     "pmg_comm_rank": (C.c_int, [vp]),
     "pmg_comm_size": (C.c_int, [vp]),
     "pmg_layout_set_comm": (C.c_int, [vp, vp, C.c_int32, c_ip, c_ip, c_ip]),

@@ -168,6 +168,17 @@ extern "C" int pmg_comm_allgather(pmg_comm c, const void* send, size_t bytes, vo
   return PMG_OK;
 }
 
+// values[0 .. n) (device) summed over the ranks in place, stream-ordered on `stream`
+extern "C" int pmg_comm_allreduce_sum(pmg_comm c, double* values, int n, pmg_stream stream)
+{
+  PMG_REQUIRE(c && values && n >= 0, "pmg_comm_allreduce_sum: bad argument");
+  if (n == 0)
+    return PMG_OK;
+  pmg_layout_s l;
+  l.comm = c;
+  return comm_allreduce(&l, values, n, false, S(stream));
+}
+
 extern "C" int pmg_comm_rank(pmg_comm c) { return c ? c->rank : -1; }
 extern "C" int pmg_comm_size(pmg_comm c) { return c ? c->nranks : -1; }
 

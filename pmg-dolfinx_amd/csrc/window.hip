@@ -466,7 +466,7 @@ extern "C" int pmg_layout_set_windows(pmg_layout l, int32_t n_neighbors, const i
 // A communicator made of windows: the reductions (and the set-up gathers) without a transport library.
 //
 // Every rank owns one window of PMG_COMM_WINDOW_BYTES which all ranks map; an exchange of up to
-// WC_CHUNK doubles per rank is two kernels on the caller's stream, as for the halo:
+// PMG_COMM_WINDOW_CHUNK doubles per rank is two kernels on the caller's stream, as for the halo:
 //   put : stores my values into slot [number & 1][my rank] of EVERY rank's window (my own included), one system-scope
 //         fence per workgroup, and the last workgroup raises arrived[slot][my rank] = number at every rank;
 //   get : waits for arrived[slot][r] >= number from all ranks r, then combines the R contributions in rank order
@@ -479,7 +479,7 @@ extern "C" int pmg_layout_set_windows(pmg_layout l, int32_t n_neighbors, const i
 namespace
 {
 constexpr int WC_MAXR = PMG_COMM_WINDOW_MAX_RANKS;
-constexpr int WC_CHUNK = 4096; // doubles per rank and exchange
+constexpr int WC_CHUNK = PMG_COMM_WINDOW_CHUNK; // doubles per rank and exchange
 struct CommWindow              // the layout of a rank's window
 {
   uint64_t arrived[2][WC_MAXR];
@@ -583,7 +583,7 @@ __global__ void wcomm_get_kernel(const WCommDev* __restrict__ wp, int m, double*
 int wc_blocks(long long items)
 {
   const long long b = (items + 4 * 256 - 1) / (4 * 256);
-  return (int)(b < 1 ? 1 : (b > 64 ? 64 : b));
+  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
 }
 } // namespace
 

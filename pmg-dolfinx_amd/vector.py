@@ -188,7 +188,7 @@ class WindowComm:
 
     halo = "windows"
     distributed = True
-    WINDOW_BYTES = 8 * (2 * 16 + 8 + 2 * 16 * 4096)
+    WINDOW_BYTES = 8 * (2 * 16 + 8 + 2 * 16 * 16384)  # PMG_COMM_WINDOW_BYTES
 
     def __init__(self, rank: int, size: int, gather, host=None):
         import os
