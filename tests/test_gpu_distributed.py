@@ -221,6 +221,7 @@ def _worker_body(rank, world, port, n, dims, orders, halo="exchange"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("PMG_WINDOW_TIMEOUT_MS", "20000")  # the ranks time-slice one GPU: generous, still bounded
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import pmg_dolfinx_amd as pm
