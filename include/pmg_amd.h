@@ -164,6 +164,8 @@ int pmg_layout_set_comm(pmg_layout l, pmg_comm comm, int32_t n_neighbors, const 
 #define PMG_WINDOW_ERR_NO_ARRIVAL 1
 #define PMG_WINDOW_ERR_SLOT_BUSY 2
 int pmg_window_alloc(size_t bytes, void** ptr, char* handle /* [PMG_WINDOW_HANDLE_BYTES] */);
+/* 1: the last pmg_window_alloc of this process obtained fine-grained device memory, 0: ordinary, -1: none yet */
+int pmg_window_fine_grained(void);
 int pmg_window_open(const char* handle, void** ptr);
 int pmg_window_close(void* ptr);
 int pmg_window_free(void* ptr);

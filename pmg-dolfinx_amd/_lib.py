@@ -54,6 +54,7 @@ _SIGS = {
     "pmg_comm_size": (C.c_int, [vp]),
     "pmg_layout_set_comm": (C.c_int, [vp, vp, C.c_int32, c_ip, c_ip, c_ip]),
     "pmg_window_alloc": (C.c_int, [C.c_size_t, C.POINTER(vp), C.c_char_p]),
+    "pmg_window_fine_grained": (C.c_int, []),
     "pmg_window_open": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "pmg_window_close": (C.c_int, [vp]),
     "pmg_window_free": (C.c_int, [vp]),

@@ -288,6 +288,8 @@ int window_exchange_end(pmg_layout l, bool reverse, double* x, hipStream_t s)
 } // namespace pmg
 
 // ---- window memory ----
+static int g_window_fine_grained = -1; // what the last pmg_window_alloc of this process obtained
+extern "C" int pmg_window_fine_grained(void) { return g_window_fine_grained; }
 static_assert(sizeof(hipIpcMemHandle_t) == PMG_WINDOW_HANDLE_BYTES, "pmg window handle size");
 
 extern "C" int pmg_window_alloc(size_t bytes, void** ptr, char* handle)
@@ -296,6 +298,7 @@ extern "C" int pmg_window_alloc(size_t bytes, void** ptr, char* handle)
   void* p = nullptr;
   // fine-grained: stores of another GPU must be visible to a kernel that is already running here
   hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+  g_window_fine_grained = e == hipSuccess ? 1 : 0;
   if (e != hipSuccess)
   {
     (void)hipGetLastError();
@@ -307,6 +310,19 @@ extern "C" int pmg_window_alloc(size_t bytes, void** ptr, char* handle)
   hipIpcMemHandle_t h;
   if (e == hipSuccess)
     e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess && g_window_fine_grained == 1) // a runtime that cannot export fine-grained memory: ordinary memory
+  {
+    (void)hipGetLastError();
+    (void)hipFree(p);
+    p = nullptr;
+    g_window_fine_grained = 0;
+    PMG_HIP(hipMalloc(&p, bytes));
+    e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess)
+      e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+      e = hipIpcGetMemHandle(&h, p);
+  }
   if (e != hipSuccess)
   {
     (void)hipFree(p);

@@ -46,6 +46,7 @@ def worker(rank, world, port, q):
     t_big = (time.perf_counter() - t0) / 20
     dist.barrier()
     if rank == 0:
+        print("window memory fine-grained:", _lib.lib().pmg_window_fine_grained(), flush=True)
         q.put((world, t_dot, t_big))
     dist.destroy_process_group()
 
