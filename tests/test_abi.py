@@ -7,6 +7,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 from oracle import pmg_oracle as po
 
@@ -91,3 +92,31 @@ def test_cpp_adapter_drivers_build_and_fail_loudly_without_gpu(built):
         r = subprocess.run([os.path.join(root, "pmg-dolfinx_amd", "bin", "mat_free_main"), "--n", "2"],
                            capture_output=True, text=True, timeout=60)
         assert r.returncode == 1 and "error:" in r.stderr
+
+
+def test_halo_window_plan_is_host_arithmetic(built):
+    """pmg_layout_window_describe (no GPU involved): every neighbour's segment starts on a 256-byte boundary, the
+    ghost -> owner region follows the owner -> ghost region, two slots; more neighbours than the flag block serves are
+    refused with a message."""
+    import ctypes as C
+
+    import numpy as np
+
+    from pmg_dolfinx_amd import _lib
+
+    send = np.array([37, 1001, 64, 0], dtype=np.int32)
+    recv = np.array([5, 33, 0, 700], dtype=np.int32)
+    doubles, fwd, rev = C.c_int64(), np.zeros(4, np.int64), np.zeros(4, np.int64)
+    _lib.call("pmg_layout_window_describe", 4, send.ctypes.data_as(_lib.c_ip), recv.ctypes.data_as(_lib.c_ip),
+              C.byref(doubles), fwd.ctypes.data_as(_lib.c_lp), rev.ctypes.data_as(_lib.c_lp))
+    pad = lambda n: (n + 31) // 32 * 32  # noqa: E731 -- 32 doubles = 256 bytes
+    rlen = sum(pad(int(c)) for c in recv)
+    slen = sum(pad(int(c)) for c in send)
+    assert fwd.tolist() == [0, 32, 96, 96] and all(o % 32 == 0 for o in fwd)
+    assert rev.tolist() == [rlen, rlen + 64, rlen + 64 + 1024, rlen + 64 + 1024 + 64]
+    assert doubles.value == 2 * (rlen + slen)
+    many = np.ones(65, dtype=np.int32)
+    big = np.zeros(65, np.int64)
+    with pytest.raises(RuntimeError, match="at most 64 neighbours"):
+        _lib.call("pmg_layout_window_describe", 65, many.ctypes.data_as(_lib.c_ip), many.ctypes.data_as(_lib.c_ip),
+                  C.byref(doubles), big.ctypes.data_as(_lib.c_lp), big.ctypes.data_as(_lib.c_lp))
