@@ -119,6 +119,8 @@ def parse_args(argv=None):
     ap.add_argument("--rehearse-comm", action="store_true",
                     help="N = 1: run the multi-rank code path (process group, communicator bootstrap, strong-scaling "
                          "block) with a group of one rank -- a rehearsal on a single-GPU box, not a measurement")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the BASELINE config-5 measurement (p = 6 -> 3 -> 1 with the AMG coarse solve)")
     ap.add_argument("--mesh-sweep", action="store_true",
                     help="N = 1: PCG iteration counts at 32^3 / 64^3 / 96^3 with a random right-hand side")
     return ap.parse_args(argv)
@@ -558,12 +560,48 @@ def main():
             del cg, xs, rr
         out["pcg"] = res
 
+    # ---- BASELINE config 5: p = 6 -> 3 -> 1 with the AMG coarse solve at p = 1 inside the V-cycle (the reference:
+    # hypre BoomerAMG, src/amg.hpp; here csrc/amg.hip, two stationary cycles), ~17 M dofs per GPU (43^3 hexes).  Extra,
+    # not `value`; its parity is the small-mesh tests' (tests/test_gpu_distributed.py, orders (1, 3, 6)).
+    def _config5():
+        n5 = 43
+        dims5 = dims
+        H5 = pm.PoissonHierarchy(tuple(n5 * d for d in dims5), (1, 3, 6), kappa=2.0, cheb_its=args.cheb, proc_dims=dims5,
+                                 rank=rank, size=world, comm=comm)
+        t_setup = time.perf_counter()
+        if multi:
+            amg5 = pm.AmgSolver(H5.operators[0], global_index=H5.levels[0].local_to_global,
+                                n_global=H5.part.global_ndofs(1), cycles=2)
+        else:
+            amg5 = pm.AmgSolver(H5.operators[0], cycles=2)
+        torch.cuda.synchronize()
+        setup_s = time.perf_counter() - t_setup
+        H5.mg.set_coarse_solver(amg5)
+        x5 = H5.new_vector()
+        x5.set(0.0)
+        rns = [H5.mg.apply(H5.rhs[-1], x5, verbose=True) for _ in range(6)]
+        for _ in range(2):
+            H5.mg.apply(H5.rhs[-1], x5)
+        t5 = timed_cycles(H5, H5.rhs[-1], x5, args.steps)
+        nd5 = H5.part.global_ndofs(6)
+        out["config5"] = {"workload": f"Poisson p=6 V-cycle p=6->3->1, Chebyshev({args.cheb})/Jacobi, AMG (2 stationary "
+                                      f"cycles) on the p=1 level, {n5}^3 hexes per GPU",
+                          "value": nd5 * args.steps / t5, "unit": "DoF/s", "ms_per_step": 1e3 * t5 / args.steps,
+                          "fine_dofs_global": nd5,
+                          "residual_contraction_per_cycle": [round(rns[i + 1] / rns[i], 4) for i in range(5)],
+                          "amg_levels": amg5.info(), "amg_setup_seconds": round(setup_s, 3)}
+        H5.mg.set_coarse_solver(None)
+        del amg5, x5, H5
+
     extras = world == 1 or args.extras  # the scaling runs measure the headline only
     if extras:
         with extra(out, "amg_coarse"):
             _amg_coarse()
         with extra(out, "pcg"):
             _pcg()
+        if not args.no_config5:
+            with extra(out, "config5"):
+                _config5()
 
     # ---- h-independence of the outer PCG with a random right-hand side (extra, --mesh-sweep, N = 1) ----
     def _mesh_sweep():
