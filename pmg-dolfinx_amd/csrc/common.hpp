@@ -205,7 +205,7 @@ void launch_pointwise(int n, double* w, const double* x, const double* y, hipStr
 void launch_cheb_init(int n, double* r, double* z, const double* b, const double* q,
                       const double* dinv, double c0, hipStream_t s, double* clear_q = nullptr, int n_total = 0);
 void launch_cheb_step(int n, double* x, double* r, double* z, const double* q, const double* dinv,
-                      double c1, double c2, bool both, bool x_final, hipStream_t s, double* clear_q = nullptr,
+                      double c1, double c2, bool both, int x_final, hipStream_t s, double* clear_q = nullptr,
                       int n_total = 0);
 void launch_cheb_residual(int n, double* r, const double* q, hipStream_t s);
 void launch_add(int n, double* x, const double* z, hipStream_t s);

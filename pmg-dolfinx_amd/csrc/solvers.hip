@@ -37,7 +37,7 @@ pmg_layout amg_layout(pmg_amg amg);
 long long amg_capture_state(pmg_amg amg);
 long long laplacian_capture_state(pmg_laplacian op);
 void launch_cheb_first(int n, double* x, double* r, double* z, const double* q, const double* dinv,
-                       double c1, double c2, bool x_final, hipStream_t s, double* clear_q = nullptr, int n_total = 0);
+                       double c1, double c2, int x_final, hipStream_t s, double* clear_q = nullptr, int n_total = 0);
 bool laplacian_wants_zeroed_output(pmg_laplacian op);
 int laplacian_apply_zeroed(pmg_laplacian op, double* in, double* out, hipStream_t s);
 } // namespace pmg
@@ -148,7 +148,12 @@ int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n,
     }
     const double c1 = (2.0 * i - 1.0) / (2.0 * i + 3.0);
     const double c2 = (8.0 * i + 4.0) / (2.0 * i + 3.0) / lmax;
-    const bool x_final = (i + 1 == max_iter); // the last correction enters x here
+    // the last correction enters x here (1); when no residual is wanted either, r and z are dead behind this step (2)
+#ifdef PMG_CHEB_KEEP_RZ // timing comparison: always write r and z
+    const int x_final = (i + 1 == max_iter) ? 1 : 0;
+#else
+    const int x_final = (i + 1 == max_iter) ? (need_r == ResidualNone ? 2 : 1) : 0;
+#endif
     if (x_zero && i == 1)
       launch_cheb_first(n, x, w.r, w.z, w.q, dinv, c1, c2, x_final, s, clear_q, n_total);
     else

@@ -262,7 +262,8 @@ struct ChebStepF
   const double* q;
   const double* dinv;
   double c1, c2;
-  int x_final; // the last correction: x is gathered next (apply / prolongation), keep it in cache
+  int x_final; // 1, 2: the last correction: x is gathered next (apply / prolongation), keep it in cache;
+               // 2: nobody reads r and z after this step (no residual wanted): they are not written
   __device__ void pair(int i) const
   {
     double2 vx = ld2<NT>(x, i), vr = ld2<NT>(r, i), vz = D2(z)[i];
@@ -282,8 +283,11 @@ struct ChebStepF
       D2(x)[i] = vx;
     else
       st2<NT>(x, i, vx);
-    st2<NT>(r, i, vr);
-    D2(z)[i] = vz;
+    if (x_final != 2)
+    {
+      st2<NT>(r, i, vr);
+      D2(z)[i] = vz;
+    }
   }
   __device__ void one(int i) const
   {
@@ -291,9 +295,12 @@ struct ChebStepF
     if constexpr (BOTH)
       vx += vz;
     double vr = r[i] - q[i];
-    r[i] = vr;
     vz = c1 * vz + c2 * dinv[i] * vr;
-    z[i] = vz;
+    if (x_final != 2)
+    {
+      r[i] = vr;
+      z[i] = vz;
+    }
     x[i] = vx + vz;
   }
 };
@@ -320,17 +327,23 @@ struct ChebFirstF
       D2(x)[i] = make_double2(vx.x + vz.x, vx.y + vz.y);
     else
       st2<NT>(x, i, make_double2(vx.x + vz.x, vx.y + vz.y));
-    st2<NT>(r, i, vr);
-    D2(z)[i] = vz;
+    if (x_final != 2)
+    {
+      st2<NT>(r, i, vr);
+      D2(z)[i] = vz;
+    }
   }
   __device__ void one(int i) const
   {
     double vz = z[i];
     const double vx = vz;
     double vr = r[i] - q[i];
-    r[i] = vr;
     vz = c1 * vz + c2 * dinv[i] * vr;
-    z[i] = vz;
+    if (x_final != 2)
+    {
+      r[i] = vr;
+      z[i] = vz;
+    }
     x[i] = vx + vz;
   }
 };
@@ -579,10 +592,10 @@ void launch_cheb_init(int n, double* r, double* z, const double* b, const double
     ew_launch(n, v, ChebInitF<false>{r, z, b, q, dinv, c0}, s);
 }
 void launch_cheb_step(int n, double* x, double* r, double* z, const double* q, const double* dinv,
-                      double c1, double c2, bool both, bool x_final, hipStream_t s, double* clear_q, int n_total)
+                      double c1, double c2, bool both, int x_final, hipStream_t s, double* clear_q, int n_total)
 {
   bool v = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(q) && aligned16(dinv);
-  const int xf = x_final ? 1 : 0;
+  const int xf = x_final;
   if (clear_q) // small levels only (merged-launch operators): no streaming variants needed
   {
     if (both)
@@ -611,10 +624,10 @@ void launch_cheb_residual(int n, double* r, const double* q, hipStream_t s)
     ew_launch(n, aligned16(r) && aligned16(q), ChebResidualF<false>{r, q}, s);
 }
 void launch_cheb_first(int n, double* x, double* r, double* z, const double* q, const double* dinv,
-                       double c1, double c2, bool x_final, hipStream_t s, double* clear_q, int n_total)
+                       double c1, double c2, int x_final, hipStream_t s, double* clear_q, int n_total)
 {
   bool v = aligned16(x) && aligned16(r) && aligned16(z) && aligned16(q) && aligned16(dinv);
-  const int xf = x_final ? 1 : 0;
+  const int xf = x_final;
   if (clear_q)
     ew_launch_clear(n, n_total, v, ChebFirstF<false>{x, r, z, q, dinv, c1, c2, xf}, clear_q, s);
   else if (streams(n))
