@@ -1240,8 +1240,15 @@ int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, h
   }
   for (int l = l0; l < l1; ++l)
   {
-    const int first = op->launch_first[l], count = op->launch_count[l];
+    int first = op->launch_first[l], count = op->launch_count[l];
     const int atomic_out = (l >= op->n_plain) ? 1 : 0; // merged launches add with atomics
+#ifdef PMG_ABL_ONE_LAUNCH // timing only (wrong sums on shared dofs): all colours of a cell list in one launch -- what do
+                          // the seven launch boundaries cost?  (profiles/kernel_tuning_r03.md section 14)
+    if (!atomic_out)
+      while (l + 1 < l1 && l + 1 < op->n_plain && (l + 1 < op->n_launch_l) == (l < op->n_launch_l)
+             && op->launch_first[l + 1] == first + count)
+        count += op->launch_count[++l];
+#endif
     switch (op->P)
     {
     case 1:
