@@ -174,9 +174,7 @@ extern "C" int pmg_comm_allreduce_sum(pmg_comm c, double* values, int n, pmg_str
   PMG_REQUIRE(c && values && n >= 0, "pmg_comm_allreduce_sum: bad argument");
   if (n == 0)
     return PMG_OK;
-  pmg_layout_s l;
-  l.comm = c;
-  return comm_allreduce(&l, values, n, false, S(stream));
+  return comm_allreduce(c, values, n, false, S(stream));
 }
 
 extern "C" int pmg_comm_rank(pmg_comm c) { return c ? c->rank : -1; }
@@ -344,7 +342,10 @@ int comm_exchange_end(pmg_layout l, hipStream_t s)
 // values[0..n) (device) summed / maximised over the ranks in place, stream-ordered on `s`
 int comm_allreduce(pmg_layout l, double* d_values, int n, bool max, hipStream_t s)
 {
-  pmg_comm c = l->comm;
+  return comm_allreduce(l->comm, d_values, n, max, s);
+}
+int comm_allreduce(pmg_comm c, double* d_values, int n, bool max, hipStream_t s)
+{
   if (c->wcomm)
     return wcomm_allreduce(c, d_values, n, max, s);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;

@@ -141,6 +141,7 @@ constexpr int RED_SLOTS = 8;
 int comm_exchange_begin(pmg_layout l, bool reverse, hipStream_t s);
 int comm_exchange_end(pmg_layout l, hipStream_t s);
 int comm_allreduce(pmg_layout l, double* d_values, int n, bool max, hipStream_t s);
+int comm_allreduce(pmg_comm c, double* d_values, int n, bool max, hipStream_t s);
 bool comm_capture_ready(pmg_layout l, bool with_allreduce);
 
 // window.hip -- the exchange of a layout that has halo windows (x: the whole vector, owned entries first)

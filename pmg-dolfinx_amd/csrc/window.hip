@@ -411,6 +411,7 @@ extern "C" int pmg_layout_set_windows(pmg_layout l, int32_t n_neighbors, const i
   window_destroy(l);
   auto* w = new pmg_window_s;
   l->win = w;
+  const int rc = [&]() -> int { // (a failure below must not leave a half-built attachment on the layout)
   std::vector<size_t> so, ro;
   const size_t rlen = segment_offsets(recv_counts, n_neighbors, ro);
   const size_t slen = segment_offsets(send_counts, n_neighbors, so);
@@ -476,6 +477,10 @@ extern "C" int pmg_layout_set_windows(pmg_layout l, int32_t n_neighbors, const i
   PMG_TRY(upload_dst(&w->rev_dst));
   PMG_TRY(upload(pos, &w->recv_pos));
   return PMG_OK;
+  }();
+  if (rc != PMG_OK)
+    window_destroy(l);
+  return rc;
 }
 
 // ==================================================================================================
