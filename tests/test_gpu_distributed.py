@@ -276,7 +276,9 @@ def test_ranks_share_one_gpu(dims, n, built):
 
 
 @pytest.mark.parametrize("route", ["windows", "window-comm"])
-@pytest.mark.parametrize("dims,n", [((1, 1, 2), (3, 4, 8)), ((1, 2, 2), (3, 4, 6))])
+@pytest.mark.parametrize("dims,n", [((1, 1, 2), (3, 4, 8)), ((1, 2, 2), (3, 4, 6)),
+                                    ((1, 1, 3), (3, 4, 9))])  # a chain: the middle rank has two neighbours, the ends
+                                                               # one -- a rank's place in its neighbours' lists differs
 def test_ranks_share_one_gpu_through_halo_windows(dims, n, route, built):
     """The same checks with the halo moved by the library's windows: every rank (a process) stores its packed
     values straight into its neighbours' interprocess-mapped windows and waits on their flags -- the whole protocol of
