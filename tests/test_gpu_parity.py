@@ -202,7 +202,11 @@ def test_cg_and_eigenvalues(pm):
 @pytest.mark.parametrize("pc,pf,n,warped", [(1, 2, (3, 2, 2), True), (2, 4, (3, 2, 2), True), (1, 3, (3, 2, 2), True),
                                             (3, 6, (3, 2, 2), True), (4, 8, (3, 2, 2), True),
                                             (2, 4, (4, 4, 16), False), (1, 2, (4, 4, 16), False),
-                                            (1, 4, (2, 4, 8), False)])
+                                            (1, 4, (2, 4, 8), False),
+                                            # fine levels whose patches are one item shared by four waves (p = 5, 8)
+                                            # or long columns (p = 6), full and cut short
+                                            (2, 5, (2, 2, 7), True), (2, 5, (2, 2, 4), False), (3, 7, (2, 2, 6), True),
+                                            (3, 6, (2, 2, 8), False), (4, 8, (2, 2, 6), False)])
 def test_transfer_parity(pm, pc, pf, n, warped, patched):
     """Both transfer implementations: the cell form (reference-shaped constructor)
     and the patch form that shares the fine operator's patches."""
