@@ -244,7 +244,8 @@ def test_transfer_parity(pm, pc, pf, n, warped, patched):
 
 
 @pytest.mark.parametrize("orders,n", [((1, 2, 4), 4), ((1, 3), 5), ((2, 4), (3, 4, 2)), ((3,), 3),
-                                      ((1, 3, 6), 3), ((1, 2, 4, 8), 3)])  # (1, 3, 6): BASELINE config 5's levels
+                                      ((1, 3, 6), 3), ((1, 2, 4, 8), 3),  # (1, 3, 6): BASELINE config 5's levels
+                                      ((1, 5), (2, 2, 7)), ((3, 7), (2, 2, 3))])
 def test_vcycle_parity(pm, orders, n):
     from oracle import pmg_oracle as po
 
