@@ -66,10 +66,17 @@ struct WindowDev // device copy of what the kernels need
   long long timeout_ticks = 0; // of wall_clock64 (100 MHz)
 };
 
+// Counters are polled with RELAXED system-scope loads (sc0 sc1: served by memory, past the caches).  An acquire would
+// add a buffer_inv sc0 sc1 -- an invalidation of this XCD's L2 -- to every poll; it is not needed, because everything
+// that is read after the counter (the window) is itself read with system-scope loads, and they are issued only after
+// the counter's value has come back.
 __device__ inline uint64_t load_sys(const uint64_t* p)
 {
-  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// a release-only fence at system scope (write the L2 back, wait): __threadfence_system() is acquire + release and
+// would also invalidate this XCD's L2 each time
+__device__ inline void release_sys() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
 __device__ inline void store_sys(uint64_t* p, uint64_t v)
 {
   __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -118,20 +125,23 @@ __global__ void window_put_kernel(const WindowDev* __restrict__ wp, int d, int n
   double* const* to = dst + (long long)(s & 1) * n;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     *to[i] = in[idx[i]];
-  // one release per block, by the thread that counts the block in: the barrier orders the block's stores before it
-  // (a fence per thread would write the L2 back a thousand times per exchange: measured 48 us per exchange against 8)
+  // One release per block, by the thread that counts the block in (a fence per thread writes the L2 back a thousand
+  // times per exchange: measured 48 us per exchange against 20).  The barrier alone does not order the OTHER waves'
+  // stores before it -- at workgroup scope the compiler waits for LDS only -- so every wave first waits for the
+  // acknowledgement of its own stores.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   __shared__ int s_last;
   if (threadIdx.x == 0)
   {
-    __threadfence_system();
+    release_sys();
     const unsigned long long prev = atomicAdd((unsigned long long*)&local[L_PACK_DONE + d], 1ull);
     s_last = prev == (unsigned long long)gridDim.x - 1;
   }
   __syncthreads();
   if (s_last && threadIdx.x < 64)
   {
-    __threadfence_system(); // every block's stores (ordered before its count) before the flags
+    release_sys(); // every block's stores (ordered before its count) before the flags
     if ((int)threadIdx.x < w.n)
       store_sys(&w.nb_flags[threadIdx.x][F_ARRIVED + d * NBMAX + w.nb_slot[threadIdx.x]], s);
     if (threadIdx.x == 0)
@@ -530,18 +540,19 @@ __global__ void wcomm_put_kernel(const WCommDev* __restrict__ wp, int m, const d
     const int r = (int)(i / m), j = (int)(i - (long long)r * m);
     w.win[r]->values[slot][w.rank][j] = src[j];
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every wave's stores acknowledged before the block is counted in
   __syncthreads();
   __shared__ int s_last;
   if (threadIdx.x == 0)
   {
-    __threadfence_system();
+    release_sys();
     const unsigned long long prev = atomicAdd((unsigned long long*)&mine->put_done, 1ull);
     s_last = prev == (unsigned long long)gridDim.x - 1;
   }
   __syncthreads();
   if (s_last && threadIdx.x < 64)
   {
-    __threadfence_system();
+    release_sys();
     if ((int)threadIdx.x < w.nranks)
       store_sys(&w.win[threadIdx.x]->arrived[slot][w.rank], n);
     if (threadIdx.x == 0)
