@@ -231,6 +231,29 @@ def _worker_body(rank, world, port, n, dims, orders, halo="exchange"):
                 "window-comm": lambda: pm.WindowComm.from_torch(),     # halo AND reductions through windows
                 "exchange": lambda: None}[halo]()
         out = _rank_checks(pm, rank, world, n, dims, orders, comm=comm)
+        if halo == "window-comm":
+            # collectives longer than one exchange of the window (16 384 doubles per rank): chunked all-reduce and gather
+            import ctypes as C
+
+            from pmg_dolfinx_amd import _lib
+
+            m = 40_000
+            v = torch.arange(m, dtype=torch.float64, device="cuda") * (rank + 1)
+            _lib.call("pmg_comm_allreduce_sum", comm.native, _lib.ptr(v), m, _lib.current_stream())
+            torch.cuda.synchronize()
+            want = np.arange(m, dtype=np.float64) * (world * (world + 1) // 2)
+            out["long_allreduce_ok"] = bool(np.array_equal(v.cpu().numpy(), want))
+            nbytes = 200_003
+            mine = np.full(nbytes, rank + 1, dtype=np.uint8)
+            mine[::1000] = np.arange(len(mine[::1000]), dtype=np.uint8)
+            got = np.zeros(nbytes * world, dtype=np.uint8)
+            _lib.call("pmg_comm_allgather", comm.native, _lib.vp(mine.ctypes.data), nbytes, _lib.vp(got.ctypes.data))
+            ok = True
+            for r in range(world):
+                ref = np.full(nbytes, r + 1, dtype=np.uint8)
+                ref[::1000] = np.arange(len(ref[::1000]), dtype=np.uint8)
+                ok = ok and np.array_equal(got[r * nbytes:(r + 1) * nbytes], ref)
+            out["long_allgather_ok"] = bool(ok)
         if halo != "exchange":
             # the same cycles replayed as a hipGraph: no host in the loop, so the ranks drift apart as far as the
             # protocol lets them (two exchanges) -- the exchange numbers kept on the device and the "consumed" counters
@@ -298,6 +321,8 @@ def test_ranks_share_one_gpu_through_halo_windows(dims, n, route, built):
     _assert_rank_results(res)
     for out in res:
         assert out["graph_replays"] >= 7 and out["graph_vs_eager"] < 1e-12, (out["graph_replays"], out["graph_vs_eager"])
+        if route == "window-comm":
+            assert out["long_allreduce_ok"] and out["long_allgather_ok"]
 
 
 # ---------------------------------------------------------------------------------------------
