@@ -21,6 +21,8 @@
 //   --graph          time the cycles as hipGraph replays (one launch per cycle; with --ranks the grouped send/recv of
 //                    every halo exchange are captured on the compute stream: no host work per exchange)
 //   --check-partition px,py,pz   host-only consistency check of the brick partition (no GPU)
+//   --node-order basix   the dofmaps handed over in basix's cell-local node order (endpoints first), as dolfinx
+//                    gives them to the reference (examples/pmg/main.cpp:83-87); same numbers as without
 //   --output FILE    write the solution as a legacy VTK file of the fine-level GLL points (:369-379)
 #define PMG_AMD_DOLFINX_NAMESPACE
 #include "../common/box_mesh.hpp"
@@ -73,6 +75,7 @@ struct Options : examples::RankOptions
   std::vector<int> orders = {1, 2, 4};
   bool pcg = false, coarse_cg = false, use_amg = false, random_rhs = false, graph = false;
   std::string output;
+  pmg_amd::NodeOrder node_order = pmg_amd::NodeOrder::ascending; // of the dofmaps handed to the library
 };
 using examples::parse3;
 
@@ -118,7 +121,12 @@ void solve(const Options& o)
     if (i == V.size() - 1) // :97 (finest space)
       std::tie(lcells, bcells) = pmg_amd::compute_boundary_cells(lv.dofmap, mesh.ncells_owned, mesh.ncells,
                                                                  nd * nd * nd, lv.size_local);
-    dofmaps_d[i].assign(lv.dofmap);
+    // --node-order basix: hand the library the dofmaps as dolfinx holds them (endpoints first per direction,
+    // examples/pmg/main.cpp:83-87); the brick partition generates them ascending
+    if (o.node_order == pmg_amd::NodeOrder::ascending)
+      dofmaps_d[i].assign(lv.dofmap);
+    else
+      dofmaps_d[i].assign(pmg_amd::dofmap_in_node_order(lv.dofmap, P, o.node_order));
     bc_markers_d[i].assign(lv.bc_marker);
     device_dofmaps[i] = dofmaps_d[i].span();
     bc_marker_d_span[i] = bc_markers_d[i].span();
@@ -133,7 +141,7 @@ void solve(const Options& o)
   {
     operators[i] = std::make_shared<acc::MatFreeLaplacian<T>>(
         order[i], device_constants, device_dofmaps[i], geom_x, geom_x_dofmap, geometry_dphi_d_span[i],
-        Gweights_d_span[i], lcells, bcells, bc_marker_d_span[i]); // :270-272
+        Gweights_d_span[i], lcells, bcells, bc_marker_d_span[i], 0, o.node_order); // :270-272
     operators[i]->compute_diag_inverse(maps[i]);                  // replaces :274-279 (no CSR)
 
     const examples::PartitionLevel& lv = V[i]->lv;
@@ -183,7 +191,7 @@ void solve(const Options& o)
   {
     matfree_interpolators[i] = std::make_shared<Interpolator<T>>(
         V[i]->element()->basix_element(), V[i + 1]->element()->basix_element(), device_dofmaps[i],
-        device_dofmaps[i + 1], lcells, bcells);
+        device_dofmaps[i + 1], lcells, bcells, o.node_order);
   }
 
   std::shared_ptr<CoarseSolverType<T>> coarse_solver; // :331-335
@@ -387,6 +395,16 @@ int main(int argc, char** argv)
       }
       else if (!std::strcmp(argv[i], "--id-file"))
         o.id_file = next();
+      else if (!std::strcmp(argv[i], "--node-order"))
+      {
+        const std::string v = next();
+        if (v == "basix" || v == "endpoints_first")
+          o.node_order = pmg_amd::NodeOrder::endpoints_first;
+        else if (v == "ascending")
+          o.node_order = pmg_amd::NodeOrder::ascending;
+        else
+          throw std::runtime_error("--node-order ascending | basix");
+      }
       else if (!std::strcmp(argv[i], "--output"))
         o.output = next();
       else if (!std::strcmp(argv[i], "--check-partition"))
@@ -397,6 +415,7 @@ int main(int argc, char** argv)
                      "           [--cycles C] [--pcg [--random-rhs]] [--amg | --amg-cycles N | --coarse-cg] [--graph]\n"
                      "           [--ranks px,py,pz [--rank r] [--id-file F]] [--native-comm] [--halo exchange|windows]\n"
                      "           [--comm rccl|windows]\n"
+                     "           [--node-order ascending|basix]\n"
                      "           [--output FILE]\n"
                      "           [--check-partition px,py,pz]\n";
         return !std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h") ? 0 : 2;

@@ -65,6 +65,41 @@ int pmg_lagrange_derivative_table(int n, double* D);
 int pmg_interpolation_table(int p_coarse, int p_fine, double* M);
 int pmg_tqli(double* d, double* e, int n);
 
+/* ---- cell-local node order --------------------------------------------------
+ * The reference takes its dofmaps from a basix tensor-product element
+ * (basix::create_tp_element, examples/pmg/main.cpp:83-87) and its 1-D tables and quadrature
+ * points from basix as well (src/laplacian.hpp:302-317, src/interpolate.hpp:118): the
+ * cell-local index is t = ja*nd^2 + jb*nd + jc in both, but the 1-D index j runs over the
+ * nodes in BASIX order -- vertex 0, vertex 1, then the interior nodes from left to right
+ * ("endpoints first"; that the dofs and the GLL points share this order is why "phi is the
+ * identity" in src/laplacian.hpp:200-202).  The kernels of this library index nodes by
+ * ASCENDING coordinate.  Every entry point that receives or returns an array indexed by a
+ * cell-local node or quadrature-point number therefore has an `_ordered` form that takes
+ * the caller's order; the library applies it ONCE, at construction, where the caller's
+ * arrays are turned into its own (a permuted copy of the dofmap: 4 N bytes per cell, held
+ * by the handle), so the kernels and everything behind them are unaffected.
+ *
+ *   PMG_NODES_ASCENDING       j = position by coordinate (the plain entry points)
+ *   PMG_NODES_ENDPOINTS_FIRST basix: j = 0 -> x = 0, j = 1 -> x = 1, j >= 2 -> interior node j - 1
+ *   PMG_NODES_CUSTOM          perm1d[j] = ascending position of the caller's 1-D node j, j < degree + 1
+ *
+ * Arrays affected: dofmap (operator, interpolator), dphi_geometry [3][nq][8] and G_weights [nq]
+ * when the caller supplies them, the geometry tensor returned by pmg_laplacian_get_geometry
+ * ([ncells][nq][6], q in the operator's node order).  NOT affected: vectors and everything indexed by
+ * a (global or local) dof number -- bc_marker, f and b of pmg_laplacian_assemble_rhs, diag_inv --,
+ * the vertex order of geom_dofmap (two nodes per direction: both orders coincide), cell lists.
+ * pmg_node_permutation writes perm1d[degree + 1] for any of the three orders (custom: validated copy).
+ * The *_ordered table functions return what basix would: points / weights / D rows and columns /
+ * M rows (fine) and columns (coarse) in the given order. */
+#define PMG_NODES_ASCENDING 0
+#define PMG_NODES_ENDPOINTS_FIRST 1
+#define PMG_NODES_CUSTOM 2
+int pmg_node_permutation(int node_order, int degree, const int32_t* custom_perm1d, int32_t* perm1d);
+int pmg_gll_table_ordered(int n, int node_order, const int32_t* custom_perm1d, double* points, double* weights);
+int pmg_lagrange_derivative_table_ordered(int n, int node_order, const int32_t* custom_perm1d, double* D);
+int pmg_interpolation_table_ordered(int p_coarse, int p_fine, int node_order, const int32_t* custom_coarse,
+                                    const int32_t* custom_fine, double* M);
+
 /* ---- distributed vector layout -------------------------------------------
  * Replaces the data members of acc::Vector (src/vector.hpp:83-96,304-324): a
  * vector is a caller-owned device array of size_local + num_ghosts doubles
@@ -223,7 +258,9 @@ int pmg_vec_norm(pmg_layout l, const double* a, int norm_type, double* result, p
  * pointers except the two cell lists, which are host arrays like the
  * reference's std::vector<int>:
  *   kappa          [ncells]               DG-0 coefficient per cell
- *   dofmap         [ncells * (degree+1)^3] local dof of (cell, t), t = a*nd^2+b*nd+c
+ *   dofmap         [ncells * (degree+1)^3] local dof of (cell, t), t = a*nd^2+b*nd+c with a, b, c the
+ *                  node numbers along x, y, z by ASCENDING coordinate (a basix / dolfinx dofmap numbers
+ *                  the 1-D nodes endpoints first: use pmg_laplacian_create_ordered for it)
  *   xgeom          [3 * npoints]          vertex coordinates
  *   geom_dofmap    [8 * ncells]           cell vertices, tensor-product order k = i*4+j*2+l
  *   bc_marker      [size_local+num_ghosts] 1 on Dirichlet dofs
@@ -252,6 +289,18 @@ int pmg_laplacian_create_with_tables(pmg_laplacian* out, pmg_layout layout, int 
                                      const double* G_weights, const int32_t* lcells,
                                      int32_t n_lcells, const int32_t* bcells, int32_t n_bcells,
                                      const int8_t* bc_marker, pmg_stream stream);
+/* The same for a caller whose cell-local node numbering is not ascending (see "cell-local node order"
+ * above): `dofmap`, and dphi_geometry / G_weights when given (both may be NULL), are indexed in
+ * `node_order`; custom_perm1d [degree + 1] only for PMG_NODES_CUSTOM.  A dolfinx / basix caller passes
+ * PMG_NODES_ENDPOINTS_FIRST with the arrays exactly as the reference's constructor receives them
+ * (src/laplacian.hpp:289-297).  The operator keeps its own ascending copy of the dofmap. */
+int pmg_laplacian_create_ordered(pmg_laplacian* out, pmg_layout layout, int degree, int32_t ncells,
+                                 const double* kappa, const int32_t* dofmap, const double* xgeom, int32_t npoints,
+                                 const int32_t* geom_dofmap, const double* dphi_geometry, const double* G_weights,
+                                 const int32_t* lcells, int32_t n_lcells, const int32_t* bcells, int32_t n_bcells,
+                                 const int8_t* bc_marker, int node_order, const int32_t* custom_perm1d,
+                                 pmg_stream stream);
+int pmg_laplacian_node_order(pmg_laplacian op); /* PMG_NODES_* the operator was created with */
 int pmg_laplacian_destroy(pmg_laplacian op);
 /* operator()(in, out), :462-482: zeroes `out` (ghosts included), updates the
  * ghosts of `in` (side effect, as in the reference), interior cells overlap
@@ -265,7 +314,8 @@ int pmg_laplacian_set_diag_inverse(pmg_laplacian op, const double* diag_inv, pmg
  * (examples/pmg/main.cpp:274-279, src/csr.hpp:100-110).  BC rows give 1. */
 int pmg_laplacian_compute_diag_inverse(pmg_laplacian op, pmg_stream stream);
 /* The precomputed geometry tensor in the reference's layout [ncells][nq][6]
- * (:99-111), for parity tests.  `G_out` is a device array. */
+ * (:99-111), for parity tests.  `G_out` is a device array; q = ja*nd^2 + jb*nd + jc in the node order
+ * the operator was created with (ascending unless pmg_laplacian_create_ordered said otherwise). */
 int pmg_laplacian_get_geometry(pmg_laplacian op, double* G_out, pmg_stream stream);
 /* GLL-collocated load vector b_i = sum_cells kappa * w_q * detJ_q * f_i at q = i
  * (what dolfinx assemble_vector does for L = inner(f, v)*dx with the GLL rule,
@@ -364,6 +414,16 @@ int pmg_interpolator_create_with_operator(pmg_interpolator* out, pmg_layout layo
                                           const int32_t* lcells, int32_t n_lcells,
                                           const int32_t* bcells, int32_t n_bcells,
                                           pmg_laplacian fine_operator, pmg_stream stream);
+/* The same with both dofmaps in the caller's cell-local node order (see "cell-local node order"; the
+ * reference's Interpolator receives the dofmaps of two basix tensor-product spaces, src/interpolate.hpp:104-107,
+ * and its operator from basix::compute_interpolation_operator in that order, :118).  custom_* [degree + 1] only for
+ * PMG_NODES_CUSTOM.  fine_operator may be NULL; if given, it may have been created in any node order. */
+int pmg_interpolator_create_ordered(pmg_interpolator* out, pmg_layout layout_coarse, pmg_layout layout_fine,
+                                    int degree_coarse, int degree_fine, int32_t ncells,
+                                    const int32_t* dofmap_coarse, const int32_t* dofmap_fine,
+                                    const int32_t* lcells, int32_t n_lcells, const int32_t* bcells,
+                                    int32_t n_bcells, pmg_laplacian fine_operator, int node_order,
+                                    const int32_t* custom_coarse, const int32_t* custom_fine, pmg_stream stream);
 int pmg_interpolator_destroy(pmg_interpolator ip);
 /* interpolate(Q1_vector, Q2_vector), :186-239: prolongation, updates the ghosts of `coarse`. */
 int pmg_interpolator_interpolate(pmg_interpolator ip, double* coarse, double* fine,

@@ -46,6 +46,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <random>
 #include <span>
 #include <stdexcept>
 #include <string>
@@ -55,6 +56,17 @@
 
 namespace pmg_amd
 {
+/// Identity of this process among the ranks that exchange window handles: a random token (pid in the low bits), not
+/// the bare pid -- ranks in different PID namespaces can share a pid.
+inline std::uint64_t process_token()
+{
+  static const std::uint64_t token = [] {
+    std::random_device rd;
+    return ((std::uint64_t)rd() << 32) ^ ((std::uint64_t)rd() << 11) ^ (std::uint64_t)getpid();
+  }();
+  return token;
+}
+
 inline void check(int rc)
 {
   if (rc != PMG_OK)
@@ -143,8 +155,8 @@ public:
   struct WindowHandle
   {
     char handle[PMG_WINDOW_HANDLE_BYTES] = {};
-    std::int32_t pid = 0;
-    void* pointer = nullptr; // meaningful inside process `pid` only
+    std::uint64_t pid = 0;   // process_token() of the owner
+    void* pointer = nullptr; // meaningful inside that process only
   };
   /// A communicator without a transport library: `allgather` hands this rank's WindowHandle to every rank and returns
   /// all of them in rank order -- once, at set-up, by whatever means the caller has (files, MPI_Allgather, a socket).
@@ -152,7 +164,7 @@ public:
   {
     WindowHandle mine;
     check(pmg_window_alloc(PMG_COMM_WINDOW_BYTES, &_window, mine.handle));
-    mine.pid = (std::int32_t)getpid();
+    mine.pid = process_token();
     mine.pointer = _window;
     const std::vector<WindowHandle> all = allgather(mine);
     if ((int)all.size() != size)
@@ -270,11 +282,12 @@ private:
   // IndexMaps in the same order).
   struct WindowRecord
   {
-    std::int32_t n = 0, pid = 0;
+    std::int32_t n = 0;
+    std::uint64_t pid = 0; // process_token() of the owner
     std::int32_t neighbors[PMG_WINDOW_MAX_NEIGHBORS] = {};
     std::int64_t doubles = 0, fwd[PMG_WINDOW_MAX_NEIGHBORS] = {}, rev[PMG_WINDOW_MAX_NEIGHBORS] = {};
     char window[PMG_WINDOW_HANDLE_BYTES] = {}, flags[PMG_WINDOW_HANDLE_BYTES] = {};
-    void *window_ptr = nullptr, *flags_ptr = nullptr; // meaningful inside process `pid` only
+    void *window_ptr = nullptr, *flags_ptr = nullptr; // meaningful inside that process only
   };
   void attach_windows(std::span<const std::int32_t> neighbors, std::span<const std::int32_t> send_counts,
                       std::span<const std::int32_t> recv_counts)
@@ -285,7 +298,7 @@ private:
     check(pmg_window_alloc(sizeof(double) * (std::size_t)mine->doubles, &_window, mine->window));
     check(pmg_window_alloc(sizeof(std::uint64_t) * PMG_WINDOW_FLAG_WORDS, &_flags, mine->flags));
     mine->n = n;
-    mine->pid = (std::int32_t)getpid();
+    mine->pid = process_token();
     mine->window_ptr = _window;
     mine->flags_ptr = _flags;
     for (int k = 0; k < n; ++k)
@@ -367,6 +380,41 @@ compute_boundary_cells(std::span<const std::int32_t> dofmap, std::int32_t ncells
     (mark ? boundary_cells : local_cells).push_back(c);
   }
   return {std::move(local_cells), std::move(boundary_cells)};
+}
+
+/// Cell-local node order of the dofmaps (and of dphi_geometry / G_weights) a caller hands over -- pmg_amd.h,
+/// "cell-local node order".  `ascending`: nodes numbered by coordinate along every direction;
+/// `endpoints_first`: the order of a basix tensor-product element, vertex 0, vertex 1, interior left to right
+/// (what dolfinx's create_functionspace gives the reference, examples/pmg/main.cpp:83-87).  The constructors
+/// default to default_node_order: endpoints_first under PMG_AMD_DOLFINX_NAMESPACE (a translation unit written
+/// against dolfinx), ascending otherwise (the self-contained drivers of examples/ generate ascending dofmaps);
+/// define PMG_AMD_DEFAULT_NODE_ORDER (0 / 1) to choose explicitly.
+enum class NodeOrder : int
+{
+  ascending = PMG_NODES_ASCENDING,
+  endpoints_first = PMG_NODES_ENDPOINTS_FIRST
+};
+#if defined(PMG_AMD_DEFAULT_NODE_ORDER)
+inline constexpr NodeOrder default_node_order = static_cast<NodeOrder>(PMG_AMD_DEFAULT_NODE_ORDER);
+#elif defined(PMG_AMD_DOLFINX_NAMESPACE)
+inline constexpr NodeOrder default_node_order = NodeOrder::endpoints_first;
+#else
+inline constexpr NodeOrder default_node_order = NodeOrder::ascending;
+#endif
+/// The caller's array [ncells][nd^3] (ascending) as a caller in basix order would hold it, and back -- for
+/// drivers and tests that generate their own meshes.
+inline std::vector<std::int32_t> dofmap_in_node_order(std::span<const std::int32_t> dofmap, int degree,
+                                                      NodeOrder order)
+{
+  const int nd = degree + 1, N = nd * nd * nd;
+  std::vector<std::int32_t> p1(nd), out(dofmap.size());
+  check(pmg_node_permutation(static_cast<int>(order), degree, nullptr, p1.data()));
+  for (std::size_t c = 0; c < dofmap.size() / N; ++c)
+    for (int a = 0; a < nd; ++a)
+      for (int b = 0; b < nd; ++b)
+        for (int k = 0; k < nd; ++k)
+          out[c * N + (a * nd + b) * nd + k] = dofmap[c * N + (p1[a] * nd + p1[b]) * nd + p1[k]];
+  return out;
 }
 
 /// What the Interpolator needs to know about a basix GLL Lagrange element: its degree.
@@ -557,10 +605,11 @@ public:
   MatFreeLaplacian(int degree, std::span<const T> coefficients, std::span<const std::int32_t> dofmap,
                    std::span<const T> xgeom, std::span<const std::int32_t> geometry_dofmap,
                    std::span<const T> dphi_geometry, std::span<const T> G_weights, const std::vector<int>& lcells,
-                   const std::vector<int>& bcells, std::span<const std::int8_t> bc_marker, std::size_t batch_size = 0)
+                   const std::vector<int>& bcells, std::span<const std::int8_t> bc_marker, std::size_t batch_size = 0,
+                   NodeOrder node_order = default_node_order)
       : _degree(degree), _kappa(coefficients), _dofmap(dofmap), _xgeom(xgeom), _geom_dofmap(geometry_dofmap),
         _dphi(dphi_geometry), _gw(G_weights), _lcells(lcells.begin(), lcells.end()),
-        _bcells(bcells.begin(), bcells.end()), _bc(bc_marker), _batch_size(batch_size)
+        _bcells(bcells.begin(), bcells.end()), _bc(bc_marker), _batch_size(batch_size), _node_order(node_order)
   {
     if (degree < 1 || degree > PMG_MAX_DEGREE)
       throw std::runtime_error("Unsupported degree [mat-free operator]"); // :346
@@ -615,17 +664,14 @@ public:
     {
       if ((std::size_t)map->size_local() + map->num_ghosts() != _bc.size())
         throw std::runtime_error("MatFreeLaplacian: vector size does not match the bc marker"); // cf. :479
+      // dofmap, dphi_geometry and G_weights are indexed in the caller's cell-local node order (the library keeps
+      // an ascending copy of the dofmap); without the two tables the library builds its own
       const bool tables = !_dphi.empty() && !_gw.empty();
-      if (tables)
-        check(pmg_laplacian_create_with_tables(
-            &_op, map->layout(), _degree, (std::int32_t)_kappa.size(), _kappa.data(), _dofmap.data(), _xgeom.data(),
-            (std::int32_t)(_xgeom.size() / 3), _geom_dofmap.data(), _dphi.data(), _gw.data(), _lcells.data(),
-            (std::int32_t)_lcells.size(), _bcells.data(), (std::int32_t)_bcells.size(), _bc.data(), nullptr));
-      else
-        check(pmg_laplacian_create(&_op, map->layout(), _degree, (std::int32_t)_kappa.size(), _kappa.data(),
-                                   _dofmap.data(), _xgeom.data(), (std::int32_t)(_xgeom.size() / 3),
-                                   _geom_dofmap.data(), _lcells.data(), (std::int32_t)_lcells.size(),
-                                   _bcells.data(), (std::int32_t)_bcells.size(), _bc.data(), nullptr));
+      check(pmg_laplacian_create_ordered(
+          &_op, map->layout(), _degree, (std::int32_t)_kappa.size(), _kappa.data(), _dofmap.data(), _xgeom.data(),
+          (std::int32_t)(_xgeom.size() / 3), _geom_dofmap.data(), tables ? _dphi.data() : nullptr,
+          tables ? _gw.data() : nullptr, _lcells.data(), (std::int32_t)_lcells.size(), _bcells.data(),
+          (std::int32_t)_bcells.size(), _bc.data(), static_cast<int>(_node_order), nullptr, nullptr));
       if (_batch_size != 0) // :383-396: the geometry tensor is not kept, it is recomputed batch by batch
         check(pmg_laplacian_set_geometry_batch(_op, (long long)_batch_size));
       _map = map;
@@ -645,6 +691,7 @@ private:
   std::vector<std::int32_t> _lcells, _bcells;
   std::span<const std::int8_t> _bc;
   std::size_t _batch_size;
+  NodeOrder _node_order;
   std::shared_ptr<const IndexMap> _map;
   pmg_laplacian _op = nullptr;
 };
@@ -806,15 +853,18 @@ public:
     requires requires(const Element& e) { e.degree(); }
   Interpolator(const Element& Q1_element, const Element& Q2_element, std::span<const std::int32_t> Q1_dofmap,
                std::span<const std::int32_t> Q2_dofmap, std::span<const std::int32_t> l_cells,
-               std::span<const std::int32_t> b_cells)
-      : Interpolator((int)Q1_element.degree(), (int)Q2_element.degree(), Q1_dofmap, Q2_dofmap, l_cells, b_cells)
+               std::span<const std::int32_t> b_cells, NodeOrder node_order = default_node_order)
+      : Interpolator((int)Q1_element.degree(), (int)Q2_element.degree(), Q1_dofmap, Q2_dofmap, l_cells, b_cells,
+                     node_order)
   {
   }
+  /// Both dofmaps in `node_order` (the reference's come from two basix tensor-product spaces, :104-107; its
+  /// operator from basix::compute_interpolation_operator in the same order, :118).
   Interpolator(int degree_coarse, int degree_fine, std::span<const std::int32_t> dofmap_coarse,
                std::span<const std::int32_t> dofmap_fine, std::span<const std::int32_t> lcells,
-               std::span<const std::int32_t> bcells)
+               std::span<const std::int32_t> bcells, NodeOrder node_order = default_node_order)
       : _pc(degree_coarse), _pf(degree_fine), _dmc(dofmap_coarse), _dmf(dofmap_fine),
-        _lcells(lcells.begin(), lcells.end()), _bcells(bcells.begin(), bcells.end())
+        _lcells(lcells.begin(), lcells.end()), _bcells(bcells.begin(), bcells.end()), _node_order(node_order)
   {
     if (degree_coarse < 1 || degree_fine <= degree_coarse || degree_fine > PMG_MAX_DEGREE)
       throw std::runtime_error("Interpolator: need 1 <= coarse degree < fine degree <= 8");
@@ -849,10 +899,10 @@ public:
     if (!_ip)
     {
       const std::size_t Nf = (std::size_t)(_pf + 1) * (_pf + 1) * (_pf + 1);
-      check(pmg_interpolator_create_with_operator(
+      check(pmg_interpolator_create_ordered(
           &_ip, coarse->layout(), fine->layout(), _pc, _pf, (std::int32_t)(_dmf.size() / Nf), _dmc.data(), _dmf.data(),
           _lcells.data(), (std::int32_t)_lcells.size(), _bcells.data(), (std::int32_t)_bcells.size(), fine_operator,
-          nullptr));
+          static_cast<int>(_node_order), nullptr, nullptr, nullptr));
     }
     return _ip;
   }
@@ -861,6 +911,7 @@ private:
   int _pc, _pf;
   std::span<const std::int32_t> _dmc, _dmf;
   std::vector<std::int32_t> _lcells, _bcells;
+  NodeOrder _node_order;
   pmg_interpolator _ip = nullptr;
 };
 

@@ -9,8 +9,9 @@ from .amg import AmgSolver  # noqa: F401
 from .cg import CGSolver  # noqa: F401
 from .chebyshev import Chebyshev  # noqa: F401
 from .interpolate import Interpolator  # noqa: F401
-from .laplacian import MatFreeLaplacian, set_merge_threshold  # noqa: F401
-from .mesh import BoxPartition, default_proc_dims  # noqa: F401
+from .laplacian import MatFreeLaplacian, node_permutation, set_merge_threshold  # noqa: F401
+from .mesh import (BoxPartition, basix_node_permutation, cell_permutation, default_proc_dims,  # noqa: F401
+                   dofmap_in_node_order)
 from .pmg import MultigridPreconditioner  # noqa: F401
 from .problem import PoissonHierarchy, make_layout  # noqa: F401
 from .vector import (Layout, RcclComm, TorchComm, Vector, WindowComm, axpy, copy, inner_product, norm, pointwise_mult, scale,  # noqa: F401

@@ -84,6 +84,16 @@ _SIGS = {
         [C.POINTER(vp), vp, C.c_int, C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp, c_ip, C.c_int32, c_ip,
          C.c_int32, vp, vp],
     ),
+    "pmg_laplacian_create_ordered": (
+        C.c_int,
+        [C.POINTER(vp), vp, C.c_int, C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp, c_ip, C.c_int32, c_ip,
+         C.c_int32, vp, C.c_int, c_ip, vp],
+    ),
+    "pmg_laplacian_node_order": (C.c_int, [vp]),
+    "pmg_node_permutation": (C.c_int, [C.c_int, C.c_int, c_ip, c_ip]),
+    "pmg_gll_table_ordered": (C.c_int, [C.c_int, C.c_int, c_ip, c_dp, c_dp]),
+    "pmg_lagrange_derivative_table_ordered": (C.c_int, [C.c_int, C.c_int, c_ip, c_dp]),
+    "pmg_interpolation_table_ordered": (C.c_int, [C.c_int, C.c_int, C.c_int, c_ip, c_ip, c_dp]),
     "pmg_laplacian_destroy": (C.c_int, [vp]),
     "pmg_laplacian_apply": (C.c_int, [vp, vp, vp, vp]),
     "pmg_laplacian_get_diag_inverse": (C.c_int, [vp, vp, vp]),
@@ -121,6 +131,11 @@ _SIGS = {
         C.c_int,
         [C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int32, vp, vp, c_ip, C.c_int32, c_ip, C.c_int32, vp, vp],
     ),
+    "pmg_interpolator_create_ordered": (
+        C.c_int,
+        [C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int32, vp, vp, c_ip, C.c_int32, c_ip, C.c_int32, vp, C.c_int,
+         c_ip, c_ip, vp],
+    ),
     "pmg_interpolator_interpolate_add": (C.c_int, [vp, vp, vp, vp]),
     "pmg_interpolator_destroy": (C.c_int, [vp]),
     "pmg_interpolator_interpolate": (C.c_int, [vp, vp, vp, vp]),
@@ -156,7 +171,8 @@ _SIGS = {
 
 # functions whose int return value is a count, not a status
 _COUNT_FUNCS = {"pmg_multigrid_graph_replays", "pmg_amg_num_levels", "pmg_laplacian_geometry_bytes", "pmg_comm_rank", "pmg_comm_size", "pmg_comm_capture_overlaps", "pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
-                "pmg_laplacian_degree", "pmg_laplacian_launches_per_apply", "pmg_laplacian_is_affine"}
+                "pmg_laplacian_degree", "pmg_laplacian_launches_per_apply", "pmg_laplacian_is_affine",
+                "pmg_laplacian_node_order"}
 
 _lib = None
 
@@ -182,6 +198,8 @@ def lib():
 
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
+            if os.environ.get("PMG_AMD_LIB_ALLOW_MISSING") and not hasattr(L, name):
+                continue  # tools/time_variants.sh against a library built from an older tree (A/B timing only)
             f = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
             f.restype = res
             f.argtypes = args

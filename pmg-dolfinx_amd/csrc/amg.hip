@@ -620,6 +620,7 @@ struct pmg_amg_s
   bool replicated = false;
   int32_t n_global = 0;
   int32_t* gid = nullptr;       // [size_local] device
+  double* d0_dinv = nullptr;    // [size_local + ghosts] this rank's rows of the level-0 inverse diagonal (dist0)
   double *gb = nullptr, *gx = nullptr; // [n_global] device
   double* h_stage = nullptr;    // pinned, [n_global]: the callback route of the all-reduce
   pmg_layout glayout = nullptr; // the replicated problem seen as one rank's (Krylov work vectors)
@@ -801,7 +802,10 @@ int dist_cycle(pmg_amg amg, double* x, const double* b, hipStream_t s)
   AmgLevel& l1 = amg->levels[1];
   const ChebWork w{amg->d0_r, amg->d0_z, amg->d0_q};
   const ApplyFn A = [op, s](double* in, double* out) { return laplacian_apply(op, in, out, s); };
-  const double* dinv = laplacian_diag_inv(op);
+  // The inverse diagonal of the hierarchy's OWN level-0 matrix, restricted to this rank (d0_dinv): the bound l0.lmax
+  // was computed for D^-1 A with that diagonal, and the operator's diag_inv may never have been computed or may have
+  // been replaced by the caller (pmg_laplacian_set_diag_inverse) -- ADVICE r03.
+  const double* dinv = amg->d0_dinv;
   PMG_TRY(cheb_iterate(w, A, dinv, n, l0.lmax, amg->smoother_its, x, b, ResidualUpdated, true, s)); // r = b - A x
   PMG_TRY(csr_product<0>(amg->R0l, amg->d0_r, nullptr, l1.b, s)); // this rank's share of R r
   PMG_TRY(device_allreduce_sum(amg, l1.b, l1.n, s));
@@ -1147,6 +1151,10 @@ static int amg_create(pmg_amg* out, pmg_laplacian op, const int64_t* global_inde
     PMG_TRY(alloc_d(&amg->d0_q, total));
     PMG_TRY(alloc_d(&amg->d0_b, total));
     PMG_TRY(alloc_d(&amg->d0_xc, total));
+    PMG_TRY(alloc_d(&amg->d0_dinv, total));
+    if (n > 0) // owned rows of the assembled level-0 diagonal (levels[0].dinv is indexed by global row)
+      from_global_kernel<<<(n + 255) / 256, 256, 0, s>>>(n, amg->gid, amg->levels[0].dinv, amg->d0_dinv);
+    PMG_HIP(hipGetLastError());
     PMG_TRY(pmg_cg_create(&amg->cg0, layout));
     amg->dist0 = true;
   }
@@ -1272,6 +1280,7 @@ extern "C" int pmg_amg_destroy(pmg_amg amg)
   (void)hipFree(amg->dense_inv);
   (void)hipFree(amg->xc);
   (void)hipFree(amg->gid);
+  (void)hipFree(amg->d0_dinv);
   (void)hipFree(amg->gb);
   (void)hipFree(amg->gx);
   if (amg->h_stage)

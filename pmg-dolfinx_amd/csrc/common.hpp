@@ -50,6 +50,23 @@ void gll_table(int n, double* x, double* w);
 void lagrange_derivative_table(int n, const double* x, double* D);
 void lagrange_eval_table(int nc, const double* xc, int nf, const double* xf, double* M);
 
+// Cell-local node order (pmg_amd.h "cell-local node order"; tables.hip).  perm1d[j] = ascending position of the
+// caller's 1-D node j; node_permutation validates / builds it, cell_permutation expands it to the nd^3 cell-local
+// numbers (perm3[t_caller] = t_ascending, t = ja*nd^2 + jb*nd + jc).
+int node_permutation(int node_order, int degree, const int32_t* custom, std::vector<int32_t>& perm1d);
+std::vector<int32_t> cell_permutation(int nd, const std::vector<int32_t>& perm1d);
+inline bool is_identity(const std::vector<int32_t>& p)
+{
+  for (size_t i = 0; i < p.size(); ++i)
+    if (p[i] != (int32_t)i)
+      return false;
+  return true;
+}
+// out[row * n + perm[t]] (x width) = in[row * n + t] (x width) on the device; perm is a device array of n entries
+int permute_rows_i32(long long nrows, int n, const int32_t* perm_d, const int32_t* in, int32_t* out, hipStream_t s);
+int permute_rows_f64(long long nrows, int n, int width, const int32_t* perm_d, const double* in, double* out,
+                     hipStream_t s);
+
 // Kernel-argument copy of a small dense table (<= 9x9), passed by value.
 struct Table
 {

@@ -25,8 +25,10 @@ struct pmg_interpolator_s
   pmg_layout lc = nullptr, lf = nullptr;
   int pc = 0, pf = 0, ndc = 0, ndf = 0, Nc = 0, Nf = 0;
   int32_t ncells = 0;
-  const int32_t* dmc = nullptr; // caller-owned
+  const int32_t* dmc = nullptr; // caller-owned (ascending node order), or the two copies below
   const int32_t* dmf = nullptr;
+  int32_t* dmc_own = nullptr;   // ascending copies of dofmaps given in another cell-local node order
+  int32_t* dmf_own = nullptr;   // (pmg_interpolator_create_ordered)
   double* M1 = nullptr;       // [ndf][ndc]
   double* inv_mult = nullptr; // [fine total], 1/multiplicity (src/interpolate.hpp:172-178)
   int32_t* lcells = nullptr;  // nullptr = identity
@@ -859,6 +861,66 @@ extern "C" int pmg_interpolator_create_with_operator(
   return PMG_OK;
 }
 
+// The same for dofmaps in the caller's cell-local node order (pmg_amd.h "cell-local node order"): ascending copies
+// are made once and owned by the handle; the 1-D interpolation table and every kernel stay ascending.
+extern "C" int pmg_interpolator_create_ordered(pmg_interpolator* out, pmg_layout layout_coarse, pmg_layout layout_fine,
+                                               int degree_coarse, int degree_fine, int32_t ncells,
+                                               const int32_t* dofmap_coarse, const int32_t* dofmap_fine,
+                                               const int32_t* lcells, int32_t n_lcells, const int32_t* bcells,
+                                               int32_t n_bcells, pmg_laplacian fine_operator, int node_order,
+                                               const int32_t* custom_coarse, const int32_t* custom_fine,
+                                               pmg_stream stream)
+{
+  PMG_REQUIRE(out, "pmg_interpolator_create_ordered: NULL handle");
+  PMG_REQUIRE(degree_coarse >= 1 && degree_fine > degree_coarse && degree_fine <= PMG_MAX_DEGREE,
+              "pmg_interpolator_create: need 1 <= degree_coarse < degree_fine <= %d", PMG_MAX_DEGREE);
+  PMG_REQUIRE(ncells >= 0 && (ncells == 0 || (dofmap_coarse && dofmap_fine)), "pmg_interpolator_create: NULL dofmap");
+  std::vector<int32_t> pc, pf;
+  PMG_TRY(node_permutation(node_order, degree_coarse, custom_coarse, pc));
+  PMG_TRY(node_permutation(node_order, degree_fine, custom_fine, pf));
+  hipStream_t s = S(stream);
+  int32_t* own[2] = {nullptr, nullptr};
+  const int32_t* use[2] = {dofmap_coarse, dofmap_fine};
+  auto release = [&] {
+    (void)hipFree(own[0]);
+    (void)hipFree(own[1]);
+  };
+  for (int which = 0; which < 2; ++which)
+  {
+    const std::vector<int32_t>& p1 = which ? pf : pc;
+    if (is_identity(p1) || ncells == 0)
+      continue;
+    const int nd = (int)p1.size(), N = nd * nd * nd;
+    const std::vector<int32_t> p3 = cell_permutation(nd, p1);
+    int32_t* p3_d = nullptr;
+    int rc = upload(&p3_d, p3.data(), p3.size(), s);
+    if (rc == PMG_OK && hipMalloc(&own[which], sizeof(int32_t) * (size_t)ncells * N) != hipSuccess)
+      rc = fail(PMG_ERR_HIP, "pmg_interpolator_create_ordered: out of device memory");
+    if (rc == PMG_OK)
+      rc = permute_rows_i32(ncells, N, p3_d, use[which], own[which], s);
+    if (rc == PMG_OK && hipStreamSynchronize(s) != hipSuccess)
+      rc = fail(PMG_ERR_HIP, "pmg_interpolator_create_ordered: permutation failed");
+    (void)hipFree(p3_d);
+    if (rc != PMG_OK)
+    {
+      release();
+      return rc;
+    }
+    use[which] = own[which];
+  }
+  const int rc = pmg_interpolator_create_with_operator(out, layout_coarse, layout_fine, degree_coarse, degree_fine,
+                                                       ncells, use[0], use[1], lcells, n_lcells, bcells, n_bcells,
+                                                       fine_operator, stream);
+  if (rc != PMG_OK)
+  {
+    release();
+    return rc;
+  }
+  (*out)->dmc_own = own[0];
+  (*out)->dmf_own = own[1];
+  return PMG_OK;
+}
+
 extern "C" int pmg_interpolator_interpolate_add(pmg_interpolator ip, double* coarse, double* fine,
                                                 pmg_stream stream)
 {
@@ -873,6 +935,8 @@ extern "C" int pmg_interpolator_destroy(pmg_interpolator ip)
 {
   if (!ip)
     return PMG_OK;
+  (void)hipFree(ip->dmc_own);
+  (void)hipFree(ip->dmf_own);
   (void)hipFree(ip->cpoff);
   (void)hipFree(ip->cpdofs);
   (void)hipFree(ip->clmap_id);

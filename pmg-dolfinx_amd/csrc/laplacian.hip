@@ -38,6 +38,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 using namespace pmg;
 
@@ -52,6 +53,12 @@ struct pmg_laplacian_s
   const double* xgeom = nullptr;
   const int32_t* geom_dofmap = nullptr;
   const int8_t* bc = nullptr;
+  // cell-local node order of the caller's arrays (pmg_amd.h): the kernels index nodes by ascending coordinate, so a
+  // caller in another order gets an ascending copy of its dofmap (op->dofmap then points to it) and its
+  // quadrature-indexed arrays are permuted on the way in (tables) and out (get_geometry)
+  int node_order = PMG_NODES_ASCENDING;
+  int32_t* dofmap_own = nullptr; // [ncells * N], ascending order; nullptr = the caller's array is used as it is
+  int32_t* qperm = nullptr;      // [N] device: caller's cell-local number -> ascending; nullptr = identity
   // owned
   double2* G = nullptr;        // [nslots][3][N]
   double* Gaff = nullptr;      // [nslots][6] constant tensor K K^T / detJ of each (affine) cell
@@ -134,6 +141,21 @@ struct Shape
   static_assert(MAXM <= 65535, "patch positions are 16-bit");
 };
 
+constexpr int Shape_wpc(int P)
+{
+  switch (P)
+  {
+  case 1: return Shape<1>::WPC;
+  case 2: return Shape<2>::WPC;
+  case 3: return Shape<3>::WPC;
+  case 4: return Shape<4>::WPC;
+  case 5: return Shape<5>::WPC;
+  case 6: return Shape<6>::WPC;
+  case 7: return Shape<7>::WPC;
+  default: return Shape<8>::WPC;
+  }
+}
+
 // ---- geometry: J, adj(J), det at one quadrature point (src/laplacian.hpp:72-97) ----
 __device__ inline void jacobian(const double* __restrict__ xgeom,
                                 const int32_t* __restrict__ gdofs, const double* __restrict__ dphi,
@@ -184,6 +206,14 @@ __device__ inline void jacobian(const double* __restrict__ xgeom,
 //     P = 8) follow each other in the order the group consumes them, across its items.  The group streams them
 //     through a ring of LDS slots with LDS-direct loads (stiffness_ring_kernel below).
 __host__ __device__ constexpr bool gflat(int nd) { return nd == 3; } // P = 2 only
+//   dense (gdense(), round 4): [patch][item][layer c][pair][cell of the item][a*nd+b] with NO padding and DIRECT per-lane
+//     loads -- lane (cell of the item, a, b) of the item's waves reads element `lane` of the (item, layer, pair) run, so a
+//     load instruction covers one contiguous run of 16 * CW * nd^2 bytes (800 B at P = 4) instead of CW runs of
+//     16 * nd^2 bytes that lie 48 N bytes apart (two misaligned 400-byte runs at P = 4); no LDS hand-over.
+#ifndef PMG_GDENSE_MASK // bit P set = dense layout at degree P
+#define PMG_GDENSE_MASK 0
+#endif
+__host__ __device__ constexpr bool gdense(int nd) { return !gflat(nd) && ((PMG_GDENSE_MASK >> (nd - 1)) & 1); }
 __host__ __device__ constexpr int gcw(int nd) // cells of an item (Shape<P>::CW)
 {
   return nd == 6 ? 7 : nd == 9 ? 3 : nd * nd <= 64 ? 64 / (nd * nd) : 1;
@@ -241,6 +271,8 @@ __host__ __device__ constexpr long long gpatch(int nd, int K)
 {
   if (gring(nd))
     return (long long)ring_cfg(nd).groups * ring_ipg(nd, K) * nd * 3 * gcw(nd) * nd * nd;
+  if (gdense(nd))
+    return (long long)((K + gcw(nd) - 1) / gcw(nd)) * nd * 3 * gcw(nd) * nd * nd;
   return gflat(nd) ? (long long)((K + gcw(nd) - 1) / gcw(nd)) * nd * gls(nd) : (long long)K * 3 * nd * nd * nd;
 }
 // absolute position of (patch slot, quadrature point q = (a,b,c), component pair)
@@ -256,10 +288,12 @@ __device__ __forceinline__ size_t gpos(int nd, int K, long long slot, int q, int
     return (size_t)p * gpatch(nd, K) + ((size_t)(g * ring_ipg(nd, K) + j) * nd + c) * (3 * WL) + pair * WL + ci * nsq
            + a * nd + b;
   }
-  if (!gflat(nd))
+  if (!gflat(nd) && !gdense(nd))
     return (size_t)slot * 3 * N + (c * 3 + pair) * nsq + a * nd + b;
   const long long p = slot / K;
   const int sl = (int)(slot - p * K), cw = gcw(nd), item = sl / cw, ci = sl - item * cw;
+  if (gdense(nd))
+    return (size_t)p * gpatch(nd, K) + ((size_t)(item * nd + c) * 3 + pair) * (cw * nsq) + ci * nsq + a * nd + b;
   return (size_t)p * gpatch(nd, K) + (size_t)(item * nd + c) * gls(nd) + pair * (cw * nsq) + ci * nsq + a * nd + b;
 }
 
@@ -348,8 +382,9 @@ __global__ void affine_geometry_kernel(long long nslots, const int32_t* __restri
 }
 
 // paired slot layout -> the reference's [cell][q][6]
+// (qperm: the caller's quadrature-point number -> ascending; nullptr = the caller's order is ascending)
 __global__ void geometry_export_kernel(long long slot0, long long nslots, int nd, int K,
-                                       const int32_t* __restrict__ pcell,
+                                       const int32_t* __restrict__ pcell, const int32_t* __restrict__ qperm,
                                        const double2* __restrict__ G, double* __restrict__ out)
 {
   const int nq = nd * nd * nd;
@@ -357,14 +392,15 @@ __global__ void geometry_export_kernel(long long slot0, long long nslots, int nd
   if (gid >= nslots * nq)
     return;
   long long slot = gid / nq;
-  int q = (int)(gid - slot * nq);
+  const int qc = (int)(gid - slot * nq); // the caller's number of the point
+  const int q = qperm ? qperm[qc] : qc;
   slot += slot0;
   int c = pcell[slot];
   if (c < 0)
     return;
   double2 a = G[gpos(nd, K, slot, q, 0)], b = G[gpos(nd, K, slot, q, 1)],
           d = G[gpos(nd, K, slot, q, 2)];
-  double* o = out + ((size_t)c * nq + q) * 6;
+  double* o = out + ((size_t)c * nq + qc) * 6;
   o[0] = a.x;
   o[1] = a.y;
   o[2] = b.x;
@@ -383,6 +419,59 @@ __device__ __forceinline__ void lds_barrier()
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+
+// ---- write-back of a patch's sums, shared by the kernels below --------------------------------------------
+// Round 4, read at the ISA level: written as one loop "load the list entry, branch on it, store", the write-back was six
+// DEPENDENT round trips per thread -- `global_load_dword; s_waitcnt vmcnt(0); ... global_store` per entry, and since
+// the counter retires in order every one of those waits also covered the acknowledgement of the previous entry's
+// store.  So: the list entries are re-read in ONE pass of unconditional loads (clamped index), issued by every
+// wavefront as it leaves the cell loop, BEFORE the barrier that ends the accumulation; behind the barrier the stores
+// go out back to back; the rare Dirichlet rows (y = x, src/laplacian.hpp:273-274: one more load each) come last, in a
+// pass of their own that interior patches skip.
+template <int ITER, int THREADS>
+__device__ __forceinline__ void patch_list_reload(uint32_t (&mk)[ITER], const uint32_t* __restrict__ pd, int M, int t)
+{
+#pragma unroll
+  for (int k = 0; k < ITER; ++k)
+  {
+    const int i = t + k * THREADS;
+    mk[k] = pd[i < M ? i : M - 1];
+  }
+}
+template <int ITER, int THREADS, bool NT>
+__device__ __forceinline__ void patch_write_back(const uint32_t (&mk)[ITER], int M, int t, const double* sy,
+                                                 const double* __restrict__ x, double* __restrict__ y, int atomic_out)
+{
+  bool bc_row = false;
+#pragma unroll
+  for (int k = 0; k < ITER; ++k)
+  {
+    const int i = t + k * THREADS;
+    const uint32_t dof = mk[k] & PD_MASK;
+    const bool mine = i < M;
+    if (mine && !(mk[k] & PD_BC))
+    {
+      const double v = sy[i];
+      if (atomic_out)
+        atomicAdd(&y[dof], v); // merged launch (global_atomic_add_f64)
+      else if constexpr (NT)
+        __builtin_nontemporal_store(v, &y[dof]);
+      else
+        y[dof] = v;
+    }
+    bc_row |= mine && (mk[k] & (PD_BC | PD_ACC)) == PD_BC;
+  }
+  if (__builtin_amdgcn_ballot_w64(bc_row) != 0) // wave-uniform: interior patches never enter
+  {
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+    {
+      const int i = t + k * THREADS;
+      if (i < M && (mk[k] & (PD_BC | PD_ACC)) == PD_BC)
+        y[mk[k] & PD_MASK] = x[mk[k] & PD_MASK]; // :273-274
+    }
+  }
+}
 
 // ---- the hot kernel, column form --------------------------------------
 //
@@ -445,6 +534,14 @@ constexpr bool unpaired_slice_reads(int P) { return (PMG_UNPAIRED_MASK >> P) & 1
 constexpr bool unpaired_slice_reads(int P) { return P == 5 || P == 8; }
 #endif
 
+// degrees that run on the stream form of the kernel (stiffness_stream_kernel below); bit P of the mask
+#ifndef PMG_STREAM_MASK
+#define PMG_STREAM_MASK 0
+#endif
+constexpr bool stream_form(int P)
+{
+  return ((PMG_STREAM_MASK >> P) & 1) && Shape_wpc(P) == 1 && !gflat(P + 1);
+}
 // minimum waves per SIMD the register allocation has to leave room for: two workgroups per CU up to
 // P = 4; the register-heavy degrees take what they need (profiles/kernel_resources_r02.md)
 template <int P>
@@ -569,7 +666,11 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     const int slot = it * CW + cw;
     const int slotc = slot < K ? slot : K - 1;
     const uint16_t* lm = lmaps + (size_t)table * (K * N) + (size_t)slotc * N + ab;
-    const double2* Gs = G + ((size_t)p * K + slotc) * 3 * N + ab;
+    // dense layout: the item's (layer, pair) runs of WL elements, element = the lane's (cell, column) index
+    constexpr bool DENSE = !AFF && gdense(ND);
+    constexpr int GPS = DENSE ? WL : NQ2; // stride between the three pairs of a layer
+    const double2* Gs = DENSE ? G + (size_t)p * gpatch(ND, K) + (size_t)(it < Sh::ITEMS ? it : Sh::ITEMS - 1) * (ND * 3 * WL) + lw
+                              : G + ((size_t)p * K + slotc) * 3 * N + ab;
     int l[ND];
 #pragma unroll
     for (int k = 0; k < ND; ++k)
@@ -607,9 +708,9 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
 #pragma unroll
       for (int d = 0; d < GD; ++d)
       {
-        gq[d][0] = gload<NT>(Gs + d * 3 * NQ2);
-        gq[d][1] = gload<NT>(Gs + d * 3 * NQ2 + NQ2);
-        gq[d][2] = gload<NT>(Gs + d * 3 * NQ2 + 2 * NQ2);
+        gq[d][0] = gload<NT>(Gs + d * 3 * GPS);
+        gq[d][1] = gload<NT>(Gs + d * 3 * GPS + GPS);
+        gq[d][2] = gload<NT>(Gs + d * 3 * GPS + 2 * GPS);
       }
     }
     const double kap = skap[slotc];
@@ -655,9 +756,9 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
         g45 = gq[k % GD][2];
         if (k + GD < ND) // refill the slot with layer k + GD
         {
-          gq[k % GD][0] = gload<NT>(Gs + (k + GD) * 3 * NQ2);
-          gq[k % GD][1] = gload<NT>(Gs + (k + GD) * 3 * NQ2 + NQ2);
-          gq[k % GD][2] = gload<NT>(Gs + (k + GD) * 3 * NQ2 + 2 * NQ2);
+          gq[k % GD][0] = gload<NT>(Gs + (k + GD) * 3 * GPS);
+          gq[k % GD][1] = gload<NT>(Gs + (k + GD) * 3 * GPS + GPS);
+          gq[k % GD][2] = gload<NT>(Gs + (k + GD) * 3 * GPS + 2 * GPS);
         }
       }
       q_s[ab] = u[k];
@@ -696,37 +797,22 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     for (int k = 0; k < ND; ++k)
       atomicAdd(&sy[l[k]], contributes ? Aq[k] : 0.0); // :270,277 -- in LDS (ds_add_f64)
   }
-  lds_barrier();
-
   // ---- write back (plain stores; the accumulator started from the earlier colours' y)
 #ifdef PMG_ABL_NOWB
+  lds_barrier();
   if (sy[t % MAXM] == 1.2345e-300)
     y[t] = 1.0;
   return;
 #endif
-#pragma unroll
-  for (int k = 0; k < ITER; ++k)
   {
-    const int i = t + k * THREADS;
-    if (i < M)
-    {
-      const uint32_t mk = pdofs[off + i];
-      const uint32_t dof = mk & PD_MASK;
-      if (mk & PD_BC)
-      {
-        if (!(mk & PD_ACC))
-          y[dof] = x[dof]; // :273-274
-      }
-      else if (atomic_out)
-        atomicAdd(&y[dof], sy[i]); // merged boundary launch (global_atomic_add_f64)
-      else
-      {
-        if constexpr (NT)
-          __builtin_nontemporal_store(sy[i], &y[dof]);
-        else
-          y[dof] = sy[i];
-      }
-    }
+    // (the thread index made opaque here: otherwise the list addresses are computed ahead of the cell loop and
+    // held -- or spilled -- through it)
+    int tw = t;
+    asm volatile("" : "+v"(tw));
+    uint32_t mk[ITER];
+    patch_list_reload<ITER, THREADS>(mk, pdofs + off, M, tw);
+    lds_barrier();
+    patch_write_back<ITER, THREADS, NT>(mk, M, tw, sy, x, y, atomic_out);
   }
 }
 // ---- the hot kernel, ring form (P >= 5: ring_cfg) ------------------------------------------
@@ -1055,6 +1141,233 @@ __global__ void __launch_bounds__(RShape<P>::THREADS)
   }
 }
 
+// ---- the hot kernel, stream form (round 4) ---------------------------------------------------
+//
+// The column kernel above with the G stream of a wavefront made CONTINUOUS.  Read at the ISA level the column
+// kernel keeps two layers of the tensor in flight inside an item (the compiler hoists layer k + 2 behind the fluxes
+// of layer k), but an item starts cold: the position table comes from global memory, then the first layer's values
+// are requested and waited for in full -- one exposed HBM round trip per item, two per wavefront and patch at P = 4,
+// and another one at the start of the workgroup, behind the gather's barrier.  Here
+//   * a wavefront's (item, layer) pairs form one stream: the refill behind the last two layers of an item requests
+//     the first two layers of the wavefront's next item;
+//   * the first two layers of the wavefront's first item are requested BEFORE the gather's barrier, behind the
+//     gather's own loads (the counter retires in order: the gather never waits for the tensor);
+//   * the position table of the patch is staged in LDS with the gather (one 16-byte load per thread), so an item
+//     starts with LDS latencies only;
+//   * kappa multiplies the item's five results once instead of every flux (linear: same value to rounding).
+// Beyond the end of its stream a wavefront re-reads ONE 16-byte element (every lane the same address): the load
+// counts stay static, no branch in the layer loop, no traffic.
+template <int P, bool NT>
+__global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
+    stiffness_stream_kernel(const double* __restrict__ x, double* __restrict__ y, const double2* __restrict__ G,
+                            const int32_t* __restrict__ poff, const uint32_t* __restrict__ pdofs,
+                            const int32_t* __restrict__ lmap_id, const uint16_t* __restrict__ lmaps,
+                            const int32_t* __restrict__ pcell, const int32_t* __restrict__ pncell,
+                            const double* __restrict__ kappa, const double* __restrict__ Dg, int first, int atomic_out)
+{
+  using Sh = Shape<P>;
+  constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, NQ2 = Sh::NQ2, CW = Sh::CW, NG = Sh::NG;
+  constexpr int MAXM = Sh::MAXM, THREADS = Sh::WTHREADS, ITER = Sh::WITER;
+  constexpr int WL = CW * NQ2;
+  static_assert(Sh::WPC == 1 && !gflat(ND), "stream kernel: one wavefront per item, default or dense G layout");
+  static_assert((K * N * 2) % 16 == 0, "the position table is staged in 16-byte pieces");
+  constexpr bool UNPAIRED = unpaired_slice_reads(P);
+  constexpr bool DENSE = gdense(ND);
+  constexpr int GPS = DENSE ? WL : NQ2;      // stride between the three pairs of a layer
+  constexpr int GLS = 3 * GPS;               // ... between two layers
+  constexpr int LMV = K * N * 2 / 16, LMI = (LMV + THREADS - 1) / THREADS;
+  __shared__ double sD[ND * ND];
+  __shared__ double skap[K];
+  __shared__ double sx[MAXM];
+  __shared__ double sy[MAXM];
+  __shared__ double sq[NG * WL];
+  __shared__ double sgr[NG * WL];
+  __shared__ double sgs[NG * WL];
+  __shared__ uint4 slm4[LMV]; // the patch's position table [slot][layer][a*nd+b] uint16
+
+  const int p = first + blockIdx.x;
+  const int t = threadIdx.x;
+  const int off = poff[p];
+  const int M = poff[p + 1] - off; // 1 <= M <= MAXM
+  const int table = lmap_id[p];
+  const int nc = pncell[p];
+
+  // the wavefront's lanes and its stream of items
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const bool lane_ok = lane < WL;
+  const int lw = lane_ok ? lane : WL - 1;
+  const int cw = lw / NQ2;
+  const int ab = lw - cw * NQ2;
+  const int a = ab / ND, b = ab - a * ND;
+  const int items = (nc + CW - 1) / CW;
+  const int nmy = items > wave ? (items - wave + NG - 1) / NG : 0; // items of this wavefront (uniform)
+  const double2* Gp = G + (size_t)p * gpatch(ND, K);
+  // element (layer 0, pair 0) of this lane in item `it`; beyond the stream: the patch's first element, all lanes
+  auto gitem = [&](int j) -> const double2* {
+    const int it = wave + j * NG;
+    const bool real = j < nmy;
+    if constexpr (DENSE)
+      return Gp + (real ? (size_t)it * (ND * 3 * WL) + lw : (size_t)0);
+    else
+    {
+      const int slot = it * CW + cw;
+      return Gp + (real ? (size_t)(slot < K ? slot : K - 1) * 3 * N + ab : (size_t)0);
+    }
+  };
+  double2 gq[2][3];
+  auto gfetch = [&](int s, const double2* base, int layer) {
+    gq[s][0] = gload<NT>(base + layer * GLS);
+    gq[s][1] = gload<NT>(base + layer * GLS + GPS);
+    gq[s][2] = gload<NT>(base + layer * GLS + 2 * GPS);
+  };
+
+  // ---- phase 0: gather (unconditional loads, clamped indices: counted vmcnt waits)
+  {
+    uint32_t m[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+    {
+      const int i = t + k * THREADS;
+      m[k] = pdofs[off + (i < M ? i : M - 1)];
+    }
+    const int cellk = pcell[(size_t)p * K + (t < K ? t : K - 1)];
+    const double dval = Dg[t < ND * ND ? t : ND * ND - 1];
+    const uint4* lmt = reinterpret_cast<const uint4*>(lmaps + (size_t)table * (K * N));
+    uint4 lmv[LMI];
+#pragma unroll
+    for (int k = 0; k < LMI; ++k)
+      lmv[k] = lmt[t + k * THREADS < LMV ? t + k * THREADS : LMV - 1];
+    double xv[ITER], yv[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+    {
+      const uint32_t dof = m[k] & PD_MASK;
+      const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+      xv[k] = x[dof];
+      const double* ya = acc ? (const double*)(y + dof) : (x + dof);
+      yv[k] = *ya;
+    }
+    const double kapk = kappa[cellk >= 0 ? cellk : 0];
+    // the head of the wavefront's tensor stream, behind the gather's loads
+    {
+      const double2* g0 = gitem(0);
+      gfetch(0, g0, 0);
+      gfetch(1, g0, ND > 1 ? 1 : 0);
+    }
+#pragma unroll
+    for (int k = 0; k < LMI; ++k)
+      if (t + k * THREADS < LMV)
+        slm4[t + k * THREADS] = lmv[k];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+    {
+      const int i = t + k * THREADS;
+      if (i < M)
+      {
+        const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
+        sx[i] = (m[k] & PD_BC) ? 0.0 : xv[k]; // src/laplacian.hpp:186-189
+        sy[i] = acc ? yv[k] : 0.0;
+      }
+    }
+    if (t < ND * ND)
+      sD[t] = dval;
+    for (int i = t; i < K; i += THREADS)
+      skap[i] = (i == t) ? kapk : kappa[pcell[(size_t)p * K + i] >= 0 ? pcell[(size_t)p * K + i] : 0];
+  }
+  lds_barrier();
+
+  // ---- cell loop
+  double Da[ND], Db[ND], DTa[ND], DTb[ND]; // D[a][.], D[b][.], D[.][a], D[.][b]
+#pragma unroll
+  for (int mm = 0; mm < ND; ++mm)
+  {
+    Da[mm] = sD[a * ND + mm];
+    Db[mm] = sD[b * ND + mm];
+    DTa[mm] = sD[mm * ND + a];
+    DTb[mm] = sD[mm * ND + b];
+  }
+  double* q_s = sq + wave * WL + cw * NQ2;
+  double* gr_s = sgr + wave * WL + cw * NQ2;
+  double* gs_s = sgs + wave * WL + cw * NQ2;
+  const uint16_t* slm = reinterpret_cast<const uint16_t*>(slm4);
+
+  // Slots: layer k of an item lives in slot k & 1.  On entry to an item its layers 0 and 1 are in flight in slots 0
+  // and 1; the refill behind layer k requests layer k + 2 of the item or, past its end, the layer of the NEXT item that
+  // belongs in the freed slot (for odd nd that is layer 1 first, then layer 0: every item then starts alike and one
+  // body serves the whole stream).
+  for (int j = 0; j < nmy; ++j)
+  {
+    const int it = wave + j * NG;
+    const int slot = it * CW + cw;
+    const int slotc = slot < K ? slot : K - 1;
+    const double2* gthis = gitem(j);
+    const double2* gnext = gitem(j + 1);
+    int l[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+      l[k] = slm[slotc * N + k * NQ2 + ab];
+    const double kap = skap[slotc];
+    double u[ND], Aq[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+    {
+      u[k] = sx[l[k]];
+      Aq[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+    {
+      const int s = k & 1;
+      q_s[ab] = u[k];
+      wave_fence();
+      double qr = 0.0, qs = 0.0, qt = 0.0;
+#pragma unroll
+      for (int mm = 0; mm < ND; ++mm)
+      {
+        qr += Da[mm] * slice_load<UNPAIRED>(q_s[mm * ND + b]); // d/dx: sum over a, :195-199
+        qs += Db[mm] * slice_load<UNPAIRED>(q_s[a * ND + mm]); // d/dy: sum over b, :206-210
+        qt += Dg[k * ND + mm] * u[mm];                         // d/dz: registers, uniform table, :214-218
+      }
+      const double2 g01 = gq[s][0], g23 = gq[s][1], g45 = gq[s][2];
+      const double fr = g01.x * qr + g01.y * qs + g23.x * qt; // :233 (kappa: once per item, below)
+      const double fs = g01.y * qr + g23.y * qs + g45.x * qt; // :234
+      const double ft = g23.x * qr + g45.x * qs + g45.y * qt; // :235
+      if (k + 2 < ND)
+        gfetch(s, gthis, k + 2);
+      else
+        gfetch(s, gnext, ND > 1 ? s : 0);
+      gr_s[ab] = fr;
+      gs_s[ab] = fs;
+      wave_fence();
+      double acc = 0.0;
+#pragma unroll
+      for (int mm = 0; mm < ND; ++mm)
+      {
+        acc += DTa[mm] * slice_load<UNPAIRED>(gr_s[mm * ND + b]); // :246-251
+        acc += DTb[mm] * slice_load<UNPAIRED>(gs_s[a * ND + mm]); // :255-259
+        Aq[mm] += Dg[k * ND + mm] * ft;                           // :263-267
+      }
+      Aq[k] += acc;
+      wave_fence();
+    }
+    const double kc = (lane_ok && slot < nc) ? kap : 0.0; // lanes without a cell add an exact zero
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+      atomicAdd(&sy[l[k]], kc * Aq[k]); // :270,277 -- in LDS (ds_add_f64)
+  }
+  // ---- write back (plain stores; the accumulator started from the earlier colours' y)
+  {
+    // (the thread index made opaque here: otherwise the list addresses are computed ahead of the cell loop and
+    // held -- or spilled -- through it)
+    int tw = t;
+    asm volatile("" : "+v"(tw));
+    uint32_t mk[ITER];
+    patch_list_reload<ITER, THREADS>(mk, pdofs + off, M, tw);
+    lds_barrier();
+    patch_write_back<ITER, THREADS, NT>(mk, M, tw, sy, x, y, atomic_out);
+  }
+}
+
 __global__ void zero_list_kernel(int n, const int32_t* __restrict__ idx, double* __restrict__ y)
 {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -1206,6 +1519,22 @@ int launch_stiffness(pmg_laplacian op, const double* x, double* y, int first, in
     // applications under the default policy (streams_past_the_cache; profiles/kernel_tuning_r03.md).  The affine mode
     // reads no tensor.
     const bool nt = P >= NT_FROM && op->geometry_mode != 1 && op->stream_policy;
+    if constexpr (stream_form(P))
+    {
+      if (op->geometry_mode != 1)
+      {
+        if (nt)
+          stiffness_stream_kernel<P, true><<<count, Shape<P>::WTHREADS, 0, s>>>(
+              x, y, G, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell, op->pncell, op->kappa, op->D, first,
+              atomic_out);
+        else
+          stiffness_stream_kernel<P, false><<<count, Shape<P>::WTHREADS, 0, s>>>(
+              x, y, G, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell, op->pncell, op->kappa, op->D, first,
+              atomic_out);
+        op->launches++;
+        return PMG_OK;
+      }
+    }
 #define PMG_LAUNCH_COLUMN(AFF_, NT_)                                                                                \
   stiffness_column_kernel<P, AFF_, NT_><<<count, Shape<P>::WTHREADS, 0, s>>>(                                         \
       x, y, G, op->Gaff, op->W1, op->poff, op->pdofs, op->lmap_id, op->lmaps, op->pcell, op->pncell, op->kappa, op->D,  \
@@ -1386,11 +1715,12 @@ int laplacian_apply_zeroed(pmg_laplacian op, double* in, double* out, hipStream_
 }
 } // namespace pmg
 
-extern "C" int pmg_laplacian_create_with_tables(
+extern "C" int pmg_laplacian_create_ordered(
     pmg_laplacian* out, pmg_layout layout, int degree, int32_t ncells, const double* kappa,
     const int32_t* dofmap, const double* xgeom, int32_t npoints, const int32_t* geom_dofmap,
     const double* dphi_geometry, const double* G_weights, const int32_t* lcells, int32_t n_lcells,
-    const int32_t* bcells, int32_t n_bcells, const int8_t* bc_marker, pmg_stream stream)
+    const int32_t* bcells, int32_t n_bcells, const int8_t* bc_marker, int node_order, const int32_t* custom_perm1d,
+    pmg_stream stream)
 {
   PMG_REQUIRE(out && layout, "pmg_laplacian_create: NULL handle");
   if (degree < 1 || degree > PMG_MAX_DEGREE)
@@ -1442,6 +1772,21 @@ extern "C" int pmg_laplacian_create_with_tables(
   const int nd = op->nd, N = op->N;
   const int total = layout->total();
 
+  // cell-local node order: everything below (patch tables, diagonal, load vector, the transfers and the AMG that
+  // read op->dofmap) works on an ascending dofmap; a caller in another order gets a permuted copy, made once
+  std::vector<int32_t> perm1d;
+  PMG_TRY(node_permutation(node_order, degree, custom_perm1d, perm1d));
+  op->node_order = node_order;
+  if (!is_identity(perm1d))
+  {
+    const std::vector<int32_t> p3 = cell_permutation(nd, perm1d);
+    PMG_TRY(upload(&op->qperm, p3.data(), p3.size(), s));
+    PMG_HIP(hipMalloc(&op->dofmap_own, sizeof(int32_t) * ((size_t)ncells * N ? (size_t)ncells * N : 1)));
+    PMG_TRY(permute_rows_i32(ncells, N, op->qperm, dofmap, op->dofmap_own, s));
+    PMG_HIP(hipStreamSynchronize(s)); // p3 goes out of scope
+    op->dofmap = dofmap = op->dofmap_own;
+  }
+
   // 1-D tables (basix's job in the reference, src/laplacian.hpp:302-317)
   std::vector<double> pts(nd), wts(nd), D(nd * nd);
   gll_table(nd, pts.data(), wts.data());
@@ -1454,9 +1799,17 @@ extern "C" int pmg_laplacian_create_with_tables(
   {
     PMG_HIP(hipMalloc(&op->dphi_geom, sizeof(double) * 24 * N));
     PMG_HIP(hipMalloc(&op->gweights, sizeof(double) * N));
-    PMG_HIP(hipMemcpyAsync(op->dphi_geom, dphi_geometry, sizeof(double) * 24 * N,
-                           hipMemcpyDeviceToDevice, s));
-    PMG_HIP(hipMemcpyAsync(op->gweights, G_weights, sizeof(double) * N, hipMemcpyDeviceToDevice, s));
+    if (op->qperm) // the caller's tables are indexed by ITS quadrature-point numbers
+    {
+      PMG_TRY(permute_rows_f64(3, N, 8, op->qperm, dphi_geometry, op->dphi_geom, s));
+      PMG_TRY(permute_rows_f64(1, N, 1, op->qperm, G_weights, op->gweights, s));
+    }
+    else
+    {
+      PMG_HIP(hipMemcpyAsync(op->dphi_geom, dphi_geometry, sizeof(double) * 24 * N,
+                             hipMemcpyDeviceToDevice, s));
+      PMG_HIP(hipMemcpyAsync(op->gweights, G_weights, sizeof(double) * N, hipMemcpyDeviceToDevice, s));
+    }
   }
   else
   {
@@ -1588,6 +1941,19 @@ extern "C" int pmg_laplacian_create_with_tables(
   return PMG_OK;
 }
 
+extern "C" int pmg_laplacian_create_with_tables(
+    pmg_laplacian* out, pmg_layout layout, int degree, int32_t ncells, const double* kappa,
+    const int32_t* dofmap, const double* xgeom, int32_t npoints, const int32_t* geom_dofmap,
+    const double* dphi_geometry, const double* G_weights, const int32_t* lcells, int32_t n_lcells,
+    const int32_t* bcells, int32_t n_bcells, const int8_t* bc_marker, pmg_stream stream)
+{
+  return pmg_laplacian_create_ordered(out, layout, degree, ncells, kappa, dofmap, xgeom, npoints, geom_dofmap,
+                                      dphi_geometry, G_weights, lcells, n_lcells, bcells, n_bcells, bc_marker,
+                                      PMG_NODES_ASCENDING, nullptr, stream);
+}
+
+extern "C" int pmg_laplacian_node_order(pmg_laplacian op) { return op ? op->node_order : -1; }
+
 extern "C" int pmg_laplacian_create(pmg_laplacian* out, pmg_layout layout, int degree,
                                     int32_t ncells, const double* kappa, const int32_t* dofmap,
                                     const double* xgeom, int32_t npoints,
@@ -1605,6 +1971,8 @@ extern "C" int pmg_laplacian_destroy(pmg_laplacian op)
   if (!op)
     return PMG_OK;
   (void)hipFree(op->G);
+  (void)hipFree(op->dofmap_own);
+  (void)hipFree(op->qperm);
   (void)hipFree(op->D);
   (void)hipFree(op->Gaff);
   (void)hipFree(op->W1);
@@ -1697,7 +2065,7 @@ extern "C" int pmg_laplacian_get_geometry(pmg_laplacian op, double* G_out, pmg_s
   PMG_TRY(for_each_geometry_chunk(op, s, [&](int first, int count, const double2* G) {
     const long long nslots = (long long)count * op->K, n = nslots * op->N;
     geometry_export_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((long long)first * op->K, nslots, op->nd,
-                                                                     op->K, op->pcell, G, G_out);
+                                                                     op->K, op->pcell, op->qperm, G, G_out);
   }));
   PMG_HIP(hipGetLastError());
   return PMG_OK;

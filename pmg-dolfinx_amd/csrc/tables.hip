@@ -157,6 +157,90 @@ void lagrange_eval_table(int nc, const double* xc, int nf, const double* xf, dou
       M[j * nc + k] = fabsl(v) <= 1e-12L ? 0.0 : (double)v;
     }
 }
+
+// ---- cell-local node order (pmg_amd.h) ----
+int node_permutation(int node_order, int degree, const int32_t* custom, std::vector<int32_t>& perm1d)
+{
+  PMG_REQUIRE(degree >= 1 && degree <= 63, "node order: bad degree %d", degree);
+  const int nd = degree + 1;
+  perm1d.resize(nd);
+  switch (node_order)
+  {
+  case PMG_NODES_ASCENDING:
+    for (int j = 0; j < nd; ++j)
+      perm1d[j] = j;
+    break;
+  case PMG_NODES_ENDPOINTS_FIRST: // basix interval element: vertex 0, vertex 1, interior left to right
+    perm1d[0] = 0;
+    perm1d[1] = nd - 1;
+    for (int j = 2; j < nd; ++j)
+      perm1d[j] = j - 1;
+    break;
+  case PMG_NODES_CUSTOM:
+  {
+    PMG_REQUIRE(custom, "node order: PMG_NODES_CUSTOM needs a permutation");
+    std::vector<char> seen(nd, 0);
+    for (int j = 0; j < nd; ++j)
+    {
+      PMG_REQUIRE(custom[j] >= 0 && custom[j] < nd && !seen[custom[j]],
+                  "node order: perm1d is not a permutation of 0..%d (entry %d = %d)", nd - 1, j, custom[j]);
+      seen[custom[j]] = 1;
+      perm1d[j] = custom[j];
+    }
+    break;
+  }
+  default:
+    return fail(PMG_ERR_INVALID, "node order: unknown order %d", node_order);
+  }
+  return PMG_OK;
+}
+
+std::vector<int32_t> cell_permutation(int nd, const std::vector<int32_t>& perm1d)
+{
+  std::vector<int32_t> p3((size_t)nd * nd * nd);
+  for (int a = 0; a < nd; ++a)
+    for (int b = 0; b < nd; ++b)
+      for (int c = 0; c < nd; ++c)
+        p3[(a * nd + b) * nd + c] = (perm1d[a] * nd + perm1d[b]) * nd + perm1d[c];
+  return p3;
+}
+
+namespace
+{
+template <typename T>
+__global__ void permute_rows_kernel(long long total, int n, int width, const int32_t* __restrict__ perm,
+                                    const T* __restrict__ in, T* __restrict__ out)
+{
+  const long long rw = (long long)n * width;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x)
+  {
+    const long long row = i / rw;
+    const int r = (int)(i - row * rw), t = r / width, k = r - t * width;
+    out[row * rw + (long long)perm[t] * width + k] = in[i];
+  }
+}
+template <typename T>
+int permute_rows(long long nrows, int n, int width, const int32_t* perm_d, const T* in, T* out, hipStream_t s)
+{
+  const long long total = nrows * n * width;
+  if (total <= 0)
+    return PMG_OK;
+  const long long blocks = (total + 255) / 256;
+  permute_rows_kernel<T><<<(unsigned)(blocks > 16384 ? 16384 : blocks), 256, 0, s>>>(total, n, width, perm_d, in, out);
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+} // namespace
+int permute_rows_i32(long long nrows, int n, const int32_t* perm_d, const int32_t* in, int32_t* out, hipStream_t s)
+{
+  return permute_rows<int32_t>(nrows, n, 1, perm_d, in, out, s);
+}
+int permute_rows_f64(long long nrows, int n, int width, const int32_t* perm_d, const double* in, double* out,
+                     hipStream_t s)
+{
+  return permute_rows<double>(nrows, n, width, perm_d, in, out, s);
+}
 } // namespace pmg
 
 using namespace pmg;
@@ -188,6 +272,65 @@ extern "C" int pmg_interpolation_table(int p_coarse, int p_fine, double* M)
   gll_table(p_coarse + 1, xc.data(), wc.data());
   gll_table(p_fine + 1, xf.data(), wf.data());
   lagrange_eval_table(p_coarse + 1, xc.data(), p_fine + 1, xf.data(), M);
+  return PMG_OK;
+}
+
+extern "C" int pmg_node_permutation(int node_order, int degree, const int32_t* custom_perm1d, int32_t* perm1d)
+{
+  PMG_REQUIRE(perm1d, "pmg_node_permutation: NULL output");
+  std::vector<int32_t> p;
+  PMG_TRY(node_permutation(node_order, degree, custom_perm1d, p));
+  for (size_t j = 0; j < p.size(); ++j)
+    perm1d[j] = p[j];
+  return PMG_OK;
+}
+
+// The tables as the caller's library (basix) would return them: entry (caller row q, caller column i) =
+// ascending entry (perm[q], perm[i]).
+extern "C" int pmg_gll_table_ordered(int n, int node_order, const int32_t* custom_perm1d, double* points,
+                                     double* weights)
+{
+  PMG_REQUIRE(n >= 2 && n <= 64 && points && weights, "pmg_gll_table_ordered: need 2 <= n <= 64");
+  std::vector<int32_t> p;
+  PMG_TRY(node_permutation(node_order, n - 1, custom_perm1d, p));
+  std::vector<double> x(n), w(n);
+  gll_table(n, x.data(), w.data());
+  for (int j = 0; j < n; ++j)
+  {
+    points[j] = x[p[j]];
+    weights[j] = w[p[j]];
+  }
+  return PMG_OK;
+}
+
+extern "C" int pmg_lagrange_derivative_table_ordered(int n, int node_order, const int32_t* custom_perm1d, double* D)
+{
+  PMG_REQUIRE(n >= 2 && n <= 64 && D, "pmg_lagrange_derivative_table_ordered: need 2 <= n <= 64");
+  std::vector<int32_t> p;
+  PMG_TRY(node_permutation(node_order, n - 1, custom_perm1d, p));
+  std::vector<double> x(n), w(n), Da((size_t)n * n);
+  gll_table(n, x.data(), w.data());
+  lagrange_derivative_table(n, x.data(), Da.data());
+  for (int q = 0; q < n; ++q)
+    for (int i = 0; i < n; ++i)
+      D[q * n + i] = Da[(size_t)p[q] * n + p[i]];
+  return PMG_OK;
+}
+
+extern "C" int pmg_interpolation_table_ordered(int p_coarse, int p_fine, int node_order, const int32_t* custom_coarse,
+                                               const int32_t* custom_fine, double* M)
+{
+  PMG_REQUIRE(p_coarse >= 1 && p_fine >= 1 && p_coarse <= 63 && p_fine <= 63 && M,
+              "pmg_interpolation_table_ordered: bad degrees");
+  std::vector<int32_t> pc, pf;
+  PMG_TRY(node_permutation(node_order, p_coarse, custom_coarse, pc));
+  PMG_TRY(node_permutation(node_order, p_fine, custom_fine, pf));
+  const int nc = p_coarse + 1, nf = p_fine + 1;
+  std::vector<double> Ma((size_t)nf * nc);
+  PMG_TRY(pmg_interpolation_table(p_coarse, p_fine, Ma.data()));
+  for (int j = 0; j < nf; ++j)
+    for (int k = 0; k < nc; ++k)
+      M[j * nc + k] = Ma[(size_t)pf[j] * nc + pc[k]];
   return PMG_OK;
 }
 

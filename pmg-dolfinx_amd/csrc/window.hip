@@ -125,6 +125,9 @@ __global__ void window_put_kernel(const WindowDev* __restrict__ wp, int d, int n
   double* const* to = dst + (long long)(s & 1) * n;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     *to[i] = in[idx[i]];
+  // (The count-in is an acquire-release read-modify-write at agent scope: the block that counts in last thereby
+  // acquires what the others released before their counts, so its flag stores are ordered after every block's data
+  // stores by the memory model and not only by issue order -- ADVICE r03; one fence per exchange.)
   // One release per block, by the thread that counts the block in (a fence per thread writes the L2 back a thousand
   // times per exchange: measured 48 us per exchange against 20).  The barrier alone does not order the OTHER waves'
   // stores before it -- at workgroup scope the compiler waits for LDS only -- so every wave first waits for the
@@ -135,7 +138,7 @@ __global__ void window_put_kernel(const WindowDev* __restrict__ wp, int d, int n
   if (threadIdx.x == 0)
   {
     release_sys();
-    const unsigned long long prev = atomicAdd((unsigned long long*)&local[L_PACK_DONE + d], 1ull);
+    const unsigned long long prev = __hip_atomic_fetch_add((unsigned long long*)&local[L_PACK_DONE + d], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     s_last = prev == (unsigned long long)gridDim.x - 1;
   }
   __syncthreads();
@@ -186,7 +189,7 @@ __global__ void window_get_kernel(const WindowDev* __restrict__ wp, int d, int n
   __shared__ int s_last;
   if (threadIdx.x == 0)
   {
-    const unsigned long long prev = atomicAdd((unsigned long long*)&local[L_UNPACK_DONE + d], 1ull);
+    const unsigned long long prev = __hip_atomic_fetch_add((unsigned long long*)&local[L_UNPACK_DONE + d], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     s_last = prev == (unsigned long long)gridDim.x - 1;
   }
   __syncthreads();
@@ -302,41 +305,59 @@ static int g_window_fine_grained = -1; // what the last pmg_window_alloc of this
 extern "C" int pmg_window_fine_grained(void) { return g_window_fine_grained; }
 static_assert(sizeof(hipIpcMemHandle_t) == PMG_WINDOW_HANDLE_BYTES, "pmg window handle size");
 
+// The protocol (relaxed polling, release-only fences, no L2 invalidation per poll) needs memory in which a peer GPU's
+// stores become visible to a kernel that is already running here: fine-grained device memory.  Ordinary
+// (coarse-grained) memory is NOT a silent fall-back: between two GPUs the reader can be served stale lines
+// from its L2 -- wrong halo values, not a timeout.  It is accepted only on request, PMG_WINDOW_ALLOW_COARSE=1, for runs
+// in which all ranks share ONE device (a rehearsal; one L2 path) on a runtime that cannot allocate or export
+// fine-grained memory.
+static bool window_coarse_allowed()
+{
+  const char* e = std::getenv("PMG_WINDOW_ALLOW_COARSE");
+  return e && e[0] == '1';
+}
+
 extern "C" int pmg_window_alloc(size_t bytes, void** ptr, char* handle)
 {
   PMG_REQUIRE(ptr && handle && bytes > 0, "pmg_window_alloc: bad argument");
   void* p = nullptr;
-  // fine-grained: stores of another GPU must be visible to a kernel that is already running here
+  hipIpcMemHandle_t h;
   hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+  const char* what = "hipExtMallocWithFlags(hipDeviceMallocFinegrained)";
+  if (e == hipSuccess)
+  {
+    what = "hipMemset";
+    e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess)
+      e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+    {
+      what = "hipIpcGetMemHandle of fine-grained memory";
+      e = hipIpcGetMemHandle(&h, p);
+    }
+  }
   g_window_fine_grained = e == hipSuccess ? 1 : 0;
   if (e != hipSuccess)
   {
     (void)hipGetLastError();
-    PMG_HIP(hipMalloc(&p, bytes));
-  }
-  e = hipMemset(p, 0, bytes);
-  if (e == hipSuccess)
-    e = hipDeviceSynchronize();
-  hipIpcMemHandle_t h;
-  if (e == hipSuccess)
-    e = hipIpcGetMemHandle(&h, p);
-  if (e != hipSuccess && g_window_fine_grained == 1) // a runtime that cannot export fine-grained memory: ordinary memory
-  {
-    (void)hipGetLastError();
     (void)hipFree(p);
     p = nullptr;
-    g_window_fine_grained = 0;
+    if (!window_coarse_allowed())
+      return fail(PMG_ERR_HIP,
+                  "pmg_window_alloc: %s failed (%s): no fine-grained device memory for the window.  Ordinary memory is "
+                  "not a safe substitute between GPUs (stale reads); set PMG_WINDOW_ALLOW_COARSE=1 only when all ranks "
+                  "share one device", what, hipGetErrorString(e));
     PMG_HIP(hipMalloc(&p, bytes));
     e = hipMemset(p, 0, bytes);
     if (e == hipSuccess)
       e = hipDeviceSynchronize();
     if (e == hipSuccess)
       e = hipIpcGetMemHandle(&h, p);
-  }
-  if (e != hipSuccess)
-  {
-    (void)hipFree(p);
-    return fail(PMG_ERR_HIP, "pmg_window_alloc: %s", hipGetErrorString(e));
+    if (e != hipSuccess)
+    {
+      (void)hipFree(p);
+      return fail(PMG_ERR_HIP, "pmg_window_alloc: %s", hipGetErrorString(e));
+    }
   }
   std::memcpy(handle, &h, sizeof(h));
   *ptr = p;
@@ -546,7 +567,7 @@ __global__ void wcomm_put_kernel(const WCommDev* __restrict__ wp, int m, const d
   if (threadIdx.x == 0)
   {
     release_sys();
-    const unsigned long long prev = atomicAdd((unsigned long long*)&mine->put_done, 1ull);
+    const unsigned long long prev = __hip_atomic_fetch_add((unsigned long long*)&mine->put_done, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     s_last = prev == (unsigned long long)gridDim.x - 1;
   }
   __syncthreads();
@@ -602,7 +623,7 @@ __global__ void wcomm_get_kernel(const WCommDev* __restrict__ wp, int m, double*
   __shared__ int s_last;
   if (threadIdx.x == 0)
   {
-    const unsigned long long prev = atomicAdd((unsigned long long*)&mine->get_done, 1ull);
+    const unsigned long long prev = __hip_atomic_fetch_add((unsigned long long*)&mine->get_done, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     s_last = prev == (unsigned long long)gridDim.x - 1;
     if (s_last)
     {
@@ -673,6 +694,12 @@ int wcomm_allgather(pmg_comm c, const void* send, size_t bytes, void* recv)
   PMG_TRY(wcomm_check(w));
   const size_t chunk_bytes = sizeof(double) * WC_CHUNK;
   std::vector<double> host((size_t)WC_CHUNK * (size_t)c->nranks);
+  // A set-up gather runs on the null stream.  That does NOT order it against work still queued on streams created
+  // with hipStreamNonBlocking (torch's side streams, a caller's own) -- and the exchange number lives in device memory,
+  // read when each kernel runs: a gather that overtook an all-reduce of this communicator still queued on such a
+  // stream would number its exchange differently on different ranks.  So the device is drained first;
+  // this is set-up code (window handles, unique ids), never on the hot path.
+  PMG_HIP(hipDeviceSynchronize());
   for (size_t o = 0; o < bytes; o += chunk_bytes)
   {
     const size_t b = bytes - o < chunk_bytes ? bytes - o : chunk_bytes;

@@ -7,7 +7,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import call, current_stream, ptr, vp
-from .laplacian import _dev_i32
+from .laplacian import _dev_i32, node_order_args
 from .vector import Layout, Vector
 
 
@@ -18,7 +18,8 @@ class Interpolator:
     degree."""
 
     def __init__(self, Q1_degree, Q2_degree, Q1_dofmap, Q2_dofmap, l_cells, b_cells, Q1_layout: Layout,
-                 Q2_layout: Layout, fine_operator=None):
+                 Q2_layout: Layout, fine_operator=None, node_order="ascending", perm1d_coarse=None,
+                 perm1d_fine=None):
         dev = Q2_layout.device
         self.lc, self.lf = Q1_layout, Q2_layout
         self.dmc = _dev_i32(Q1_dofmap, dev)
@@ -32,10 +33,15 @@ class Interpolator:
         h = vp()
         # with the fine-level operator the transfers share its cell patches (no atomics)
         self._fine_operator = fine_operator
-        call("pmg_interpolator_create_with_operator", C.byref(h), Q1_layout.handle, Q2_layout.handle,
+        # cell-local node order of the two dofmaps (the reference's come from basix elements: "basix")
+        code, pc = node_order_args(node_order, int(Q1_degree), perm1d_coarse)
+        _, pf = node_order_args(node_order, int(Q2_degree), perm1d_fine)
+        call("pmg_interpolator_create_ordered", C.byref(h), Q1_layout.handle, Q2_layout.handle,
              int(Q1_degree), int(Q2_degree), ncells, ptr(self.dmc), ptr(self.dmf), lc.ctypes.data_as(_lib.c_ip),
              lc.size, bc.ctypes.data_as(_lib.c_ip), bc.size,
-             fine_operator.handle if fine_operator is not None else vp(0), current_stream())
+             fine_operator.handle if fine_operator is not None else vp(0), code,
+             pc.ctypes.data_as(_lib.c_ip) if pc is not None else None,
+             pf.ctypes.data_as(_lib.c_ip) if pf is not None else None, current_stream())
         self._handle = h
 
     @property

@@ -34,6 +34,32 @@ def _dev_i8(a, device):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int8)).to(device)
 
 
+NODE_ORDERS = {"ascending": 0, "endpoints_first": 1, "basix": 1, "custom": 2}
+
+
+def node_order_args(node_order, degree, perm1d=None):
+    """(order code, int32 permutation or None) for the ``*_ordered`` entry points.  ``node_order`` is
+    "ascending", "basix" / "endpoints_first" (vertex 0, vertex 1, interior left to right: the order of a
+    basix tensor-product element, ``examples/pmg/main.cpp:83-87``) or "custom" with
+    ``perm1d[j]`` = ascending position of the caller's 1-D node ``j``."""
+    code = NODE_ORDERS[node_order] if isinstance(node_order, str) else int(node_order)
+    perm = None
+    if code == 2:
+        perm = np.ascontiguousarray(perm1d, dtype=np.int32)
+        if perm.size != degree + 1:
+            raise ValueError("perm1d needs degree + 1 entries")
+    return code, perm
+
+
+def node_permutation(node_order, degree, perm1d=None):
+    """perm1d[j] = ascending position of 1-D node j in the given order (``pmg_node_permutation``)."""
+    code, perm = node_order_args(node_order, degree, perm1d)
+    out = np.zeros(degree + 1, dtype=np.int32)
+    call("pmg_node_permutation", code, int(degree), perm.ctypes.data_as(_lib.c_ip) if perm is not None else None,
+         out.ctypes.data_as(_lib.c_ip))
+    return out
+
+
 def set_merge_threshold(patch_dofs: int):
     """Launch plan of operators created from now on: interior colours are merged into one atomic
     launch when the interior list has at most ``patch_dofs`` patch dofs (0: always coloured
@@ -54,7 +80,8 @@ class MatFreeLaplacian:
     value_type = np.float64
 
     def __init__(self, degree, coefficients, dofmap, xgeom, geometry_dofmap, lcells, bcells, bc_marker,
-                 layout: Layout, batch_size: int = 0):
+                 layout: Layout, batch_size: int = 0, node_order="ascending", perm1d=None, dphi_geometry=None,
+                 G_weights=None):
         if batch_size != 0:
             # src/laplacian.hpp:391-396 recomputes G per batch to save memory; with
             # 288 GB of HBM the tensor is always resident.
@@ -75,10 +102,18 @@ class MatFreeLaplacian:
         lc = np.ascontiguousarray(lcells, dtype=np.int32)
         bc_ = np.ascontiguousarray(bcells, dtype=np.int32)
         h = vp()
-        call("pmg_laplacian_create", C.byref(h), layout.handle, self.degree, self.ncells, ptr(self.kappa),
+        # cell-local node order of `dofmap` (and of the two tables when given): the reference's arrays come from a
+        # basix tensor-product element, i.e. "basix" (src/laplacian.hpp:289-297, examples/pmg/main.cpp:83-87)
+        self.node_order, perm = node_order_args(node_order, self.degree, perm1d)
+        self.dphi_geometry = _dev_f64(dphi_geometry, dev) if dphi_geometry is not None else None
+        self.G_weights = _dev_f64(G_weights, dev) if G_weights is not None else None
+        if (self.dphi_geometry is None) != (self.G_weights is None):
+            raise ValueError("dphi_geometry and G_weights come together (src/laplacian.hpp:293-294)")
+        call("pmg_laplacian_create_ordered", C.byref(h), layout.handle, self.degree, self.ncells, ptr(self.kappa),
              ptr(self.dofmap), ptr(self.xgeom), int(self.xgeom.numel() // 3), ptr(self.geom_dofmap),
+             ptr(self.dphi_geometry), ptr(self.G_weights),
              lc.ctypes.data_as(_lib.c_ip), lc.size, bc_.ctypes.data_as(_lib.c_ip), bc_.size, ptr(self.bc_marker),
-             current_stream())
+             self.node_order, perm.ctypes.data_as(_lib.c_ip) if perm is not None else None, current_stream())
         self._handle = h
 
     @property

@@ -71,6 +71,26 @@ def _box_points(box):
     return X.ravel(), Y.ravel(), Z.ravel()
 
 
+def basix_node_permutation(P: int) -> np.ndarray:
+    """perm1d[j] = ascending position of 1-D node j of a basix interval element: vertex 0, vertex 1, then the
+    interior nodes from left to right (the order of dolfinx's tensor-product dofmaps and of basix's GLL points)."""
+    nd = P + 1
+    return np.array([0, nd - 1] + list(range(1, nd - 1)), dtype=np.int32)[:nd]
+
+
+def cell_permutation(perm1d) -> np.ndarray:
+    """perm3[t_caller] = t_ascending for t = ja*nd^2 + jb*nd + jc."""
+    p = np.asarray(perm1d, dtype=np.int64)
+    nd = p.size
+    return ((p[:, None, None] * nd + p[None, :, None]) * nd + p[None, None, :]).ravel().astype(np.int32)
+
+
+def dofmap_in_node_order(dofmap: np.ndarray, perm1d) -> np.ndarray:
+    """The ascending dofmap [ncells, nd^3] as a caller with cell-local node order ``perm1d`` would hold it
+    (what dolfinx hands the reference for perm1d = basix_node_permutation(P))."""
+    return np.ascontiguousarray(dofmap[:, cell_permutation(perm1d)])
+
+
 @dataclass
 class LevelData:
     """Everything one p-level needs on one rank (host arrays)."""

@@ -11,7 +11,7 @@ from .cg import CGSolver
 from .chebyshev import Chebyshev
 from .interpolate import Interpolator
 from .laplacian import MatFreeLaplacian
-from .mesh import BoxPartition, default_proc_dims
+from .mesh import BoxPartition, basix_node_permutation, default_proc_dims, dofmap_in_node_order
 from .pmg import MultigridPreconditioner
 from .vector import Layout, Vector
 
@@ -23,7 +23,8 @@ def make_layout(lv, group=None, device="cuda", comm=None) -> Layout:
 
 class PoissonHierarchy:
     def __init__(self, n, orders=(1, 2, 4), kappa=2.0, cheb_its=3, proc_dims=None, rank=0, size=1, group=None,
-                 warp=None, eig_cg_its=20, eig_cg_rtol=1e-6, freq=(2, 3, 4), device="cuda", comm=None):
+                 warp=None, eig_cg_its=20, eig_cg_rtol=1e-6, freq=(2, 3, 4), device="cuda", comm=None,
+                 node_order="ascending", level_hook=None):
         import torch
 
         self.orders = tuple(int(p) for p in orders)
@@ -39,11 +40,20 @@ class PoissonHierarchy:
         self.xgeom = torch.from_numpy(part.xgeom).to(dev)
         self.geom_dofmap = torch.from_numpy(part.geom_dofmap).to(dev)
         self.kappa = torch.full((part.ncells,), float(kappa), dtype=torch.float64, device=dev)  # :190-193
+        # node_order = "basix": the dofmaps are handed over as dolfinx would hold them (endpoints first per direction)
+        self.node_order = node_order
         for P in self.orders:
             lv = part.level(P)
+            if level_hook is not None:  # bench.py --corrupt-halo: a deliberately wrong halo plan for the gate's own test
+                level_hook(lv)
             layout = make_layout(lv, group, device, comm)
-            op = MatFreeLaplacian(P, self.kappa, lv.dofmap, self.xgeom, self.geom_dofmap, lv.lcells, lv.bcells,
-                                  lv.bc_marker, layout)  # :270-272
+            dofmap = lv.dofmap
+            if node_order in ("basix", "endpoints_first"):
+                dofmap = dofmap_in_node_order(lv.dofmap, basix_node_permutation(P))
+            elif node_order != "ascending":
+                raise ValueError("PoissonHierarchy: node_order is 'ascending' or 'basix'")
+            op = MatFreeLaplacian(P, self.kappa, dofmap, self.xgeom, self.geom_dofmap, lv.lcells, lv.bcells,
+                                  lv.bc_marker, layout, node_order=node_order)  # :270-272
             op.compute_diag_inverse()  # replaces :274-279
             self.levels.append(lv)
             self.layouts.append(layout)
@@ -85,7 +95,7 @@ class PoissonHierarchy:
             self.interpolators.append(
                 Interpolator(self.orders[i], self.orders[i + 1], self.operators[i].dofmap,
                              self.operators[i + 1].dofmap, lf.lcells, lf.bcells, self.layouts[i],
-                             self.layouts[i + 1], fine_operator=self.operators[i + 1]))
+                             self.layouts[i + 1], fine_operator=self.operators[i + 1], node_order=node_order))
         # V-cycle, :348-355
         self.mg = MultigridPreconditioner(self.layouts, self.levels[0].bc_marker)
         self.mg.set_solvers(self.smoothers)

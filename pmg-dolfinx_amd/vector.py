@@ -118,6 +118,11 @@ class TorchComm:
         return r.cpu().numpy()
 
 
+# Identity of THIS process among the ranks that exchange window handles: a random token, not the pid -- ranks in
+# different PID namespaces (containers) can share a pid and would then use each other's pointers as their own.
+_PROCESS_TOKEN = int.from_bytes(__import__("os").urandom(8), "little")
+
+
 class RcclComm:
     """The library's native communicator (``pmg_comm``): the neighbour exchange is one group of
     ncclSend/ncclRecv per scatter, the reductions are ncclAllReduce on device scalars, both issued
@@ -196,11 +201,11 @@ class WindowComm:
         self.rank, self.world = int(rank), int(size)
         self._gather, self._host = gather, host
         self._window, handle = HaloWindows._alloc(self.WINDOW_BYTES)
-        everyone = gather({"handle": handle, "pid": os.getpid(), "pointer": self._window.value})
+        everyone = gather({"handle": handle, "pid": _PROCESS_TOKEN, "pointer": self._window.value})
         self._opened = []
         ptrs = (vp * self.world)()
         for r, info in enumerate(everyone):
-            if r == self.rank or info["pid"] == os.getpid():
+            if r == self.rank or info["pid"] == _PROCESS_TOKEN:
                 ptrs[r] = info["pointer"]
             else:
                 p = vp()
@@ -396,7 +401,7 @@ class HaloWindows:
         # (a window of this very process -- a rank that is its own neighbour, ranks that are threads -- is used
         # through its pointer: a process cannot open its own interprocess handle)
         mine = {"neighbors": list(L.neighbors), "doubles": int(doubles.value), "fwd": fwd[:n].tolist(),
-                "rev": rev[:n].tolist(), "window": wh, "flags": fh, "pid": os.getpid(),
+                "rev": rev[:n].tolist(), "window": wh, "flags": fh, "pid": _PROCESS_TOKEN,
                 "pointers": (self.window.value, self.flags.value)}
         everyone = comm.gather_objects(mine)
         me = int(comm.rank)
@@ -415,7 +420,7 @@ class HaloWindows:
                 raise ValueError(f"rank {r} does not list rank {me} as a neighbour as often as rank {me} lists it")
             slot = slots[j]
             if r not in mapped:
-                if info["pid"] == os.getpid():
+                if info["pid"] == _PROCESS_TOKEN:
                     mapped[r] = (vp(info["pointers"][0]), vp(info["pointers"][1]))
                 else:
                     mapped[r] = (self._open(info["window"]), self._open(info["flags"]))

@@ -120,3 +120,43 @@ def test_halo_window_plan_is_host_arithmetic(built):
     with pytest.raises(RuntimeError, match="at most 64 neighbours"):
         _lib.call("pmg_layout_window_describe", 65, many.ctypes.data_as(_lib.c_ip), many.ctypes.data_as(_lib.c_ip),
                   C.byref(doubles), big.ctypes.data_as(_lib.c_lp), big.ctypes.data_as(_lib.c_lp))
+
+
+def test_node_order_tables_are_host_arithmetic(built):
+    """pmg_node_permutation and the *_ordered tables (no GPU involved): the endpoints-first order is basix's
+    (vertex 0, vertex 1, interior left to right; the tables the reference takes from basix,
+    src/laplacian.hpp:302-317, src/interpolate.hpp:118, are these rows and columns of the ascending ones)."""
+    import pmg_dolfinx_amd as pm
+    from pmg_dolfinx_amd import _lib
+
+    ip, dp = _lib.c_ip, _lib.c_dp
+    for P in range(1, 9):
+        n = P + 1
+        perm = pm.node_permutation("basix", P)
+        assert perm.tolist() == ([0, n - 1] + list(range(1, n - 1)))[:n]
+        assert pm.node_permutation("ascending", P).tolist() == list(range(n))
+        assert np.array_equal(perm, pm.basix_node_permutation(P))
+        xo, wo = po.gll_points_weights(n)
+        x, w, D = np.zeros(n), np.zeros(n), np.zeros((n, n))
+        _lib.call("pmg_gll_table_ordered", n, 1, None, x.ctypes.data_as(dp), w.ctypes.data_as(dp))
+        assert x[0] == 0.0 and x[min(1, n - 1)] == 1.0 and np.all(np.diff(x[2:]) > 0)
+        assert np.abs(x - xo[perm]).max() < 1e-15 and np.abs(w - wo[perm]).max() < 1e-15
+        _lib.call("pmg_lagrange_derivative_table_ordered", n, 1, None, D.ctypes.data_as(dp))
+        Do = po.lagrange_deriv_matrix(xo)
+        assert np.abs(D - Do[np.ix_(perm, perm)]).max() < 1e-13 * np.abs(Do).max()
+        # ... which is the derivative table of the Lagrange basis on the PERMUTED nodes, from first principles
+        assert np.abs(D - po.lagrange_deriv_matrix(xo[perm])).max() < 1e-11 * np.abs(Do).max()
+    for pc, pf in ((1, 2), (2, 4), (3, 6), (4, 8)):
+        M = np.zeros((pf + 1, pc + 1))
+        _lib.call("pmg_interpolation_table_ordered", pc, pf, 1, None, None, M.ctypes.data_as(dp))
+        Mo = po.interpolation_matrix_1d(pc, pf)
+        assert np.abs(M - Mo[np.ix_(pm.basix_node_permutation(pf), pm.basix_node_permutation(pc))]).max() < 1e-14
+    custom = np.array([2, 0, 1], dtype=np.int32)
+    out = np.zeros(3, dtype=np.int32)
+    _lib.call("pmg_node_permutation", 2, 2, custom.ctypes.data_as(ip), out.ctypes.data_as(ip))
+    assert out.tolist() == [2, 0, 1]
+    bad = np.array([2, 2, 1], dtype=np.int32)
+    with pytest.raises(RuntimeError, match="not a permutation"):
+        _lib.call("pmg_node_permutation", 2, 2, bad.ctypes.data_as(ip), out.ctypes.data_as(ip))
+    with pytest.raises(RuntimeError, match="unknown order"):
+        _lib.call("pmg_node_permutation", 9, 2, None, out.ctypes.data_as(ip))

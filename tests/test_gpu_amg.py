@@ -200,3 +200,35 @@ def test_vcycle_with_amg_coarse_solver(pm):
     assert len(calls) == 4
     assert np.abs(x2.data_copy() - xo).max() < 1e-7 * np.abs(xo).max()
     h.mg.set_coarse_solver(None)
+
+
+def test_replicated_solver_does_not_depend_on_the_operators_stored_diagonal(pm):
+    """the replicated form smooths level 0 on the partitioned operator; it must do so with the hierarchy's
+    OWN assembled diagonal (the bound lambda_max belongs to it), not with whatever the operator holds in diag_inv --
+    which the caller may never have computed (uninitialised memory) or may have replaced (set_diag_inverse).  One
+    rank, replicated form (global index = identity), three operators: diagonal computed, never computed, replaced by
+    garbage -- the same iteration count and the same solution."""
+    n = 12
+    part = pm.BoxPartition(n, warp=twist)
+    lv = part.level(1)
+    b = np.random.default_rng(11).standard_normal(lv.ndofs)
+    b[lv.bc_marker.astype(bool)] = 0.0
+    results = []
+    for mode in ("computed", "never", "garbage"):
+        layout = pm.make_layout(lv)
+        op = pm.MatFreeLaplacian(1, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells, lv.bc_marker,
+                                 layout)
+        if mode == "computed":
+            op.compute_diag_inverse()
+        elif mode == "garbage":
+            op.set_diag_inverse(_vec(pm, layout, np.full(lv.ndofs, 1e6)))
+        amg = pm.AmgSolver(op, max_iter=60, rtol=1e-8, global_index=np.arange(lv.ndofs), n_global=lv.ndofs)
+        assert amg.num_levels() >= 2  # so that the distributed fine level is what runs
+        x = pm.Vector(layout)
+        its = amg.solve(x, _vec(pm, layout, b))
+        results.append((its, x.data_copy()))
+    its0, x0 = results[0]
+    assert its0 <= 14
+    for its, x in results[1:]:
+        assert its == its0
+        assert np.abs(x - x0).max() < 1e-9 * np.abs(x0).max()

@@ -82,6 +82,17 @@ def test_pmg_driver(built):
     assert abs(float(m.group(3)) - np.linalg.norm(xs)) < 1e-6 * np.linalg.norm(xs)
 
 
+def test_pmg_driver_with_basix_ordered_dofmaps(built):
+    """--node-order basix: the C++ adapter hands the library dofmaps in basix's cell-local node order (endpoints first
+    per direction: what dolfinx gives the reference, examples/pmg/main.cpp:83-87) through
+    pmg_laplacian_create_ordered / pmg_interpolator_create_ordered; the run reproduces the ascending run's numbers."""
+    args = ("--n", 6, "--orders", "1,2,4", "--smoother-its", 3, "--cycles", 4, "--pcg")
+    ref, out = run("pmg_main", *args), run("pmg_main", *args, "--node-order", "basix")
+    for pat in (r"Eigenvalues level \d+: \S+ - (\S+)", r"Cycle \d+: residual norm = (\S+)", r"Norm of b = (\S+)"):
+        a, b = grab(pat, ref), grab(pat, out)
+        assert len(a) == len(b) > 0 and all(abs(x - y) < 1e-9 * abs(x) for x, y in zip(a, b)), (pat, a, b)
+
+
 def test_driver_errors(built):
     path = os.path.join(BIN, "mat_free_main")
     r = subprocess.run([path, "--degree", "9"], capture_output=True, text=True, timeout=60)
