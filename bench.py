@@ -446,7 +446,7 @@ def main():
     alg_bytes = algorithmic_bytes_per_cell(P) * ncells_launch
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    for tname in ("hbm_traffic_r03.json", "hbm_traffic_r02.json", "hbm_traffic_r01.json"):
+    for tname in ("hbm_traffic_r04.json", "hbm_traffic_r03.json", "hbm_traffic_r02.json", "hbm_traffic_r01.json"):
         tfile = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tfile):
             try:
@@ -456,9 +456,41 @@ def main():
                 traffic = None
             if traffic is not None:
                 break
+    # in-run streaming ceiling of THIS box (boxes of the pool differ by a few per cent): the library's own
+    # element-wise launcher on three fine-level vectors, r = alpha x + y (two reads + one write of 8 bytes per
+    # dof; 3 x 136 MB at config 2, beyond the 256 MB Infinity Cache), HIP events on the launch stream
+    tri = [H.new_vector() for _ in range(3)]
+    for v in tri:
+        v.set(1.0)
+    for _ in range(3):
+        pm.axpy(tri[0], 0.5, tri[1], tri[2])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tri_reps = 20
+    e0.record()
+    for _ in range(tri_reps):
+        pm.axpy(tri[0], 0.5, tri[1], tri[2])
+    e1.record()
+    torch.cuda.synchronize()
+    measured_peak = 24.0 * H.levels[-1].size_local / (e0.elapsed_time(e1) / tri_reps * 1e-3) / 1e9
+    # ... and the runtime's device-to-device copy of one such vector ("hipMemcpyDtoD / triad ceiling")
+    for _ in range(3):
+        tri[0].data.copy_(tri[1].data)
+    e0.record()
+    for _ in range(tri_reps):
+        tri[0].data.copy_(tri[1].data)
+    e1.record()
+    torch.cuda.synchronize()
+    measured_copy = 16.0 * tri[0].data.numel() / (e0.elapsed_time(e1) / tri_reps * 1e-3) / 1e9
+    del tri
     roofline = {"bound": "hbm", "kernel": f"stiffness_column_kernel<{P}>",
                 "byte_model": "storedG (SURVEY.md 8d): 48N + 4N + 8 + 17U bytes per cell", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                # what a pure streaming kernel reaches on this box in this run (triad, see above), and the kernel
+                # against that
+                "measured_peak": round(measured_peak, 1), "frac_of_measured": round(achieved / measured_peak, 4),
+                "measured_peak_kernel": "r = alpha x + y on three fine-level vectors (24 bytes per dof), "
+                                        f"{tri_reps} launches, HIP events",
+                "measured_copy_peak": round(measured_copy, 1),
                 "traffic": traffic,
                 "traffic_source": f"cached rocprofv3 PMC pass ({traffic_src}), not measured in this run",
                 "algorithmic_bytes_per_launch": alg_bytes,

@@ -12,6 +12,9 @@
 //   --ranks px,py,pz   one process per GPU and brick on the library's RCCL communicator
 //                      (examples/pmg/run_ranks.sh launches the processes)
 #define PMG_AMD_DOLFINX_NAMESPACE
+// this driver generates its own mesh (examples/common/box_mesh.hpp: cell-local nodes by ascending coordinate); with
+// dolfinx-generated dofmaps the macro above alone is right: the adapter then defaults to basix's order
+#define PMG_AMD_DEFAULT_NODE_ORDER 0
 #include "../common/box_mesh.hpp"
 #include "../common/brick_partition.hpp"
 #include "../common/rank_launch.hpp"

@@ -226,6 +226,10 @@ int pmg_layout_set_windows(pmg_layout l, int32_t n_neighbors, const int32_t* sen
 /* Vector::scatter_fwd_begin / scatter_fwd_end (src/vector.hpp:186-238): owner ->
  * ghost update of x; pack/unpack run on `stream` without host synchronisation. */
 int pmg_scatter_fwd_begin(pmg_layout l, const double* x, pmg_stream stream);
+/* Forward scatters issued on the layout since its creation (one per operator application, prolongation or
+ * restriction that needs its input's ghosts; the V-cycle skips those whose ghosts are current already, see
+ * pmg_multigrid_apply).  For tests and for pricing a cycle's exchanges. */
+long long pmg_layout_forward_scatters(pmg_layout l);
 int pmg_scatter_fwd_end(pmg_layout l, double* x, pmg_stream stream);
 /* Vector::scatter_rev_begin / _end (src/vector.hpp:249-286): ghost -> owner,
  * accumulated into the owned entries.  Not used on the hot path. */
@@ -512,6 +516,12 @@ int pmg_multigrid_set_coarse_amg(pmg_multigrid mg, pmg_amg amg);
  * host synchronisation. */
 int pmg_multigrid_apply(pmg_multigrid mg, const double* rhs, double* y, double* rnorm,
                         pmg_stream stream);
+/* Exchanges of a cycle on several ranks: every operator application refreshes the ghosts of its input
+ * (src/laplacian.hpp:378,425) -- except the first application of a post-smooth when the transfers share the operator's
+ * patches: the iterate leaves its pre-smooth with current ghosts (the smoother adds the ghost entries of every applied
+ * correction), the prolongation computes the coarse correction on the ghost cells too, so u + P u_c has current ghosts
+ * without an exchange of its own.  Three levels, Chebyshev(3): 17 exchanges per cycle instead of 19.
+ * PMG_LOCAL_CORRECTION=0 in the environment restores one exchange per application. */
 /* hipGraph replay of the cycle.  With enable != 0, pmg_multigrid_apply (and the V-cycle preconditioner
  * inside pmg_cg_solve) captures the cycle's ~120 launches into a graph the first time it sees a
  * (rhs, y) pair and replays it afterwards with one hipGraphLaunch on the caller's stream: same

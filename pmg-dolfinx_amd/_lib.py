@@ -42,6 +42,7 @@ _SIGS = {
     "pmg_layout_destroy": (C.c_int, [vp]),
     "pmg_layout_size_local": (C.c_int32, [vp]),
     "pmg_layout_num_ghosts": (C.c_int32, [vp]),
+    "pmg_layout_forward_scatters": (C.c_longlong, [vp]),
     "pmg_layout_set_allreduce_max": (C.c_int, [vp, ALLREDUCE_FN]),
     "pmg_comm_unique_id": (C.c_int, [C.c_char_p]),
     "pmg_comm_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p]),
@@ -172,7 +173,7 @@ _SIGS = {
 # functions whose int return value is a count, not a status
 _COUNT_FUNCS = {"pmg_multigrid_graph_replays", "pmg_amg_num_levels", "pmg_laplacian_geometry_bytes", "pmg_comm_rank", "pmg_comm_size", "pmg_comm_capture_overlaps", "pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
                 "pmg_laplacian_degree", "pmg_laplacian_launches_per_apply", "pmg_laplacian_is_affine",
-                "pmg_laplacian_node_order"}
+                "pmg_laplacian_node_order", "pmg_layout_forward_scatters"}
 
 _lib = None
 

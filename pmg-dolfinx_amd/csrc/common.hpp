@@ -144,6 +144,7 @@ struct pmg_layout_s
   // reduction scratch (owned)
   double* d_partials = nullptr; // [RED_BLOCKS] block partials + [RED_SLOTS] results
   double* h_result = nullptr;   // pinned, [RED_SLOTS]
+  long long fwd_scatters = 0; // forward scatters issued (pmg_layout_forward_scatters: exchange bookkeeping tests)
   bool multi_rank() const { return comm != nullptr || allreduce != nullptr; }
   int32_t total() const { return size_local + num_ghosts; }
 };
@@ -203,9 +204,16 @@ enum : int
 // A_zeroed (optional): the same operator for an output vector that is already zero over [0, n_total) -- given for
 // an operator whose launch accumulates with atomics; the smoother's vector kernels then clear w.q behind themselves
 // and every application after the first goes through A_zeroed (no zero-fill kernels).
+// Ghost bookkeeping of the iterate (several ranks; round 4): every operator application refreshes the ghost entries of
+// its INPUT (src/laplacian.hpp:378,425), so the ghosts of z are current right behind A z.  With track_ghosts the
+// smoother adds them to the ghost entries of x there (a kernel over the ghost range only) -- after a smooth that
+// returns its residual, in which every correction has been applied to, x then has current ghosts without an exchange
+// of its own.  A_first (optional): the operator for the FIRST application, A x, when the caller knows that x's ghosts
+// are current already (no exchange).
 int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n, double lmax, int max_iter,
                  double* x, const double* b, int need_r, bool x_zero, hipStream_t s, bool* split = nullptr,
-                 const ApplyFn* A_zeroed = nullptr, int n_total = 0);
+                 const ApplyFn* A_zeroed = nullptr, int n_total = 0, bool track_ghosts = false,
+                 const ApplyFn* A_first = nullptr);
 
 // vector.hip -- stream-ordered building blocks used by the solvers
 // local dot of the owned entries into the result slot `slot` of the layout (device)

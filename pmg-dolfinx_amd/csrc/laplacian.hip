@@ -473,6 +473,37 @@ __device__ __forceinline__ void patch_write_back(const uint32_t (&mk)[ITER], int
   }
 }
 
+// ---- diagnostic build only (-DPMG_STAMPS): where a wavefront spends its time -----------------------------------
+// Every wavefront keeps up to eight readings of the constant 100 MHz clock (s_memrealtime: 10 ns ticks) in scalar
+// registers and lane 0 stores them once, at its end, to a buffer of their own: [workgroup][wavefront][8].  No stamp
+// executes in the product build; the timings of a stamped build are read for their SHARES only
+// (cdna_hip_programming.md, In-kernel stamps).
+#ifdef PMG_STAMPS
+__device__ unsigned long long* g_stamp_buffer = nullptr;
+__device__ int g_stamp_capacity = 0; // workgroups the buffer has room for
+#define PMG_STAMP_DECL unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PMG_STAMP(i)                                                                                                  \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    stamp_[i] = __builtin_amdgcn_s_memrealtime();                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+  } while (0)
+#define PMG_STAMP_FLUSH(nwaves)                                                                                       \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* 7: the stores of the write-back are acknowledged */            \
+    PMG_STAMP(7);                                                                                                     \
+    if ((threadIdx.x & 63) == 0 && g_stamp_buffer && (int)blockIdx.x < g_stamp_capacity)                              \
+      for (int i_ = 0; i_ < 8; ++i_)                                                                                  \
+        g_stamp_buffer[((size_t)blockIdx.x * (nwaves) + (threadIdx.x >> 6)) * 8 + i_] = stamp_[i_];                   \
+  } while (0)
+#else
+#define PMG_STAMP_DECL
+#define PMG_STAMP(i)
+#define PMG_STAMP_FLUSH(nwaves)
+#endif
+
 // ---- the hot kernel, column form --------------------------------------
 //
 // One workgroup per patch, NW wavefronts.  Phase 0 / write-back as in the block
@@ -534,6 +565,11 @@ constexpr bool unpaired_slice_reads(int P) { return (PMG_UNPAIRED_MASK >> P) & 1
 constexpr bool unpaired_slice_reads(int P) { return P == 5 || P == 8; }
 #endif
 
+// degrees whose kernel keeps the patch's dof list in LDS for the write-back (4 bytes per patch dof)
+#ifndef PMG_LIST_LDS_MASK
+#define PMG_LIST_LDS_MASK 0
+#endif
+constexpr bool list_in_lds(int P) { return (PMG_LIST_LDS_MASK >> P) & 1; }
 // degrees that run on the stream form of the kernel (stiffness_stream_kernel below); bit P of the mask
 #ifndef PMG_STREAM_MASK
 #define PMG_STREAM_MASK 0
@@ -567,6 +603,11 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   __shared__ double skap[K];
   __shared__ double sx[MAXM];
   __shared__ double sy[MAXM];
+  // The patch's dof list, kept for the write-back (round 4): under load a dependent global load costs ~2 us even when
+  // it hits in L2 (in-kernel stamps, profiles/kernel_tuning_r04.md), and re-reading the list was one such round trip
+  // per workgroup behind its closing barrier.
+  constexpr bool LIST_IN_LDS = list_in_lds(P);
+  __shared__ uint32_t sm[LIST_IN_LDS ? MAXM : 1];
   __shared__ double sq[NG * WL];
   __shared__ double sgr[NG * WL];
   __shared__ double sgs[NG * WL];
@@ -575,6 +616,8 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   constexpr int FL = 3 * WL, NJ = (FL + 63) / 64, LS = gls(ND);
   __shared__ double2 sgb[FLAT ? NG * NJ * 64 : 1];
 
+  PMG_STAMP_DECL;
+  PMG_STAMP(0); // entry
   const int p = first + blockIdx.x;
   const int t = threadIdx.x;
   const int off = poff[p];
@@ -618,6 +661,8 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
         const bool acc = !atomic_out && (m[k] & (PD_ACC | PD_BC)) == PD_ACC;
         sx[i] = (m[k] & PD_BC) ? 0.0 : xv[k]; // src/laplacian.hpp:186-189
         sy[i] = acc ? yv[k] : 0.0;
+        if constexpr (LIST_IN_LDS)
+          sm[i] = m[k];
       }
     }
     if (t < ND * ND)
@@ -625,7 +670,9 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     for (int i = t; i < K; i += THREADS)
       skap[i] = (i == t) ? kapk : kappa[pcell[(size_t)p * K + i] >= 0 ? pcell[(size_t)p * K + i] : 0];
   }
+  PMG_STAMP(1); // gathered values written to LDS
   lds_barrier();
+  PMG_STAMP(2); // behind the gather's barrier
 
   // ---- cell loop: each wave on its own
   // (nd^2 > 64, i.e. P = 8: WPC waves share a cell, the slices are exchanged between
@@ -663,6 +710,10 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
 
   for (int it = wave; it < items; it += NG)
   {
+#ifdef PMG_STAMPS
+    if (it >= wave + NG)
+      PMG_STAMP(3); // first item done (overwritten by later items: the start of the LAST item)
+#endif
     const int slot = it * CW + cw;
     const int slotc = slot < K ? slot : K - 1;
     const uint16_t* lm = lmaps + (size_t)table * (K * N) + (size_t)slotc * N + ab;
@@ -804,16 +855,52 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     y[t] = 1.0;
   return;
 #endif
+#ifdef PMG_ABL_SERIAL_WB // A/B timing only: the write-back as it was up to round 3 (list entry re-read inside the branch)
+  lds_barrier();
+#pragma unroll
+  for (int k = 0; k < ITER; ++k)
+  {
+    const int i = t + k * THREADS;
+    if (i < M)
+    {
+      const uint32_t mk = pdofs[off + i];
+      const uint32_t dof = mk & PD_MASK;
+      if (mk & PD_BC)
+      {
+        if (!(mk & PD_ACC))
+          y[dof] = x[dof];
+      }
+      else if (atomic_out)
+        atomicAdd(&y[dof], sy[i]);
+      else if constexpr (NT)
+        __builtin_nontemporal_store(sy[i], &y[dof]);
+      else
+        y[dof] = sy[i];
+    }
+  }
+#else
   {
     // (the thread index made opaque here: otherwise the list addresses are computed ahead of the cell loop and
     // held -- or spilled -- through it)
+    PMG_STAMP(4); // cell loop done
     int tw = t;
     asm volatile("" : "+v"(tw));
     uint32_t mk[ITER];
-    patch_list_reload<ITER, THREADS>(mk, pdofs + off, M, tw);
+    if constexpr (!LIST_IN_LDS)
+      patch_list_reload<ITER, THREADS>(mk, pdofs + off, M, tw);
     lds_barrier();
+    if constexpr (LIST_IN_LDS)
+    {
+#pragma unroll
+      for (int k = 0; k < ITER; ++k)
+        mk[k] = sm[tw + k * THREADS < M ? tw + k * THREADS : M - 1];
+    }
+    PMG_STAMP(5); // behind the barrier that ends the accumulation
     patch_write_back<ITER, THREADS, NT>(mk, M, tw, sy, x, y, atomic_out);
+    PMG_STAMP(6); // stores issued
+    PMG_STAMP_FLUSH(Sh::NW);
   }
+#endif
 }
 // ---- the hot kernel, ring form (P >= 5: ring_cfg) ------------------------------------------
 //
@@ -1154,7 +1241,7 @@ __global__ void __launch_bounds__(RShape<P>::THREADS)
 //     gather's own loads (the counter retires in order: the gather never waits for the tensor);
 //   * the position table of the patch is staged in LDS with the gather (one 16-byte load per thread), so an item
 //     starts with LDS latencies only;
-//   * kappa multiplies the item's five results once instead of every flux (linear: same value to rounding).
+//   * kappa multiplies the item's five input values once instead of every flux (linear: same value to rounding).
 // Beyond the end of its stream a wavefront re-reads ONE 16-byte element (every lane the same address): the load
 // counts stay static, no branch in the layer loop, no traffic.
 template <int P, bool NT>
@@ -1180,11 +1267,13 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   __shared__ double skap[K];
   __shared__ double sx[MAXM];
   __shared__ double sy[MAXM];
-  __shared__ double sq[NG * WL];
-  __shared__ double sgr[NG * WL];
-  __shared__ double sgs[NG * WL];
+  // the three nd x nd slices of a wavefront's item (values, x flux, y flux) side by side: their addresses differ by
+  // constants that fold into the DS instructions' offset fields (three address registers instead of seven)
+  __shared__ double ssl[NG * 3 * WL];
   __shared__ uint4 slm4[LMV]; // the patch's position table [slot][layer][a*nd+b] uint16
 
+  PMG_STAMP_DECL;
+  PMG_STAMP(0); // entry
   const int p = first + blockIdx.x;
   const int t = threadIdx.x;
   const int off = poff[p];
@@ -1202,23 +1291,25 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   const int items = (nc + CW - 1) / CW;
   const int nmy = items > wave ? (items - wave + NG - 1) / NG : 0; // items of this wavefront (uniform)
   const double2* Gp = G + (size_t)p * gpatch(ND, K);
-  // element (layer 0, pair 0) of this lane in item `it`; beyond the stream: the patch's first element, all lanes
-  auto gitem = [&](int j) -> const double2* {
+  // Element (layer 0, pair 0) of this lane in its j-th item, as a 32-bit offset from the patch's tensor (a scalar
+  // base + 32-bit lane offsets: 64-bit per-lane pointers cost two registers each, and a spilled one is reloaded with a
+  // wait that drains the whole stream); beyond the stream: the patch's first element, every lane the same.
+  auto gitem = [&](int j) -> unsigned {
     const int it = wave + j * NG;
     const bool real = j < nmy;
     if constexpr (DENSE)
-      return Gp + (real ? (size_t)it * (ND * 3 * WL) + lw : (size_t)0);
+      return real ? (unsigned)(it * (ND * 3 * WL) + lw) : 0u;
     else
     {
       const int slot = it * CW + cw;
-      return Gp + (real ? (size_t)(slot < K ? slot : K - 1) * 3 * N + ab : (size_t)0);
+      return real ? (unsigned)((slot < K ? slot : K - 1) * 3 * N + ab) : 0u;
     }
   };
   double2 gq[2][3];
-  auto gfetch = [&](int s, const double2* base, int layer) {
-    gq[s][0] = gload<NT>(base + layer * GLS);
-    gq[s][1] = gload<NT>(base + layer * GLS + GPS);
-    gq[s][2] = gload<NT>(base + layer * GLS + 2 * GPS);
+  auto gfetch = [&](int s, unsigned base, int layer) {
+    gq[s][0] = gload<NT>(Gp + (base + (unsigned)(layer * GLS)));
+    gq[s][1] = gload<NT>(Gp + (base + (unsigned)(layer * GLS + GPS)));
+    gq[s][2] = gload<NT>(Gp + (base + (unsigned)(layer * GLS + 2 * GPS)));
   };
 
   // ---- phase 0: gather (unconditional loads, clamped indices: counted vmcnt waits)
@@ -1248,12 +1339,14 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
       yv[k] = *ya;
     }
     const double kapk = kappa[cellk >= 0 ? cellk : 0];
+#ifndef PMG_STREAM_NO_EARLY
     // the head of the wavefront's tensor stream, behind the gather's loads
     {
-      const double2* g0 = gitem(0);
+      const unsigned g0 = gitem(0);
       gfetch(0, g0, 0);
       gfetch(1, g0, ND > 1 ? 1 : 0);
     }
+#endif
 #pragma unroll
     for (int k = 0; k < LMI; ++k)
       if (t + k * THREADS < LMV)
@@ -1274,7 +1367,9 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     for (int i = t; i < K; i += THREADS)
       skap[i] = (i == t) ? kapk : kappa[pcell[(size_t)p * K + i] >= 0 ? pcell[(size_t)p * K + i] : 0];
   }
+  PMG_STAMP(1); // gathered values written to LDS
   lds_barrier();
+  PMG_STAMP(2); // behind the gather's barrier
 
   // ---- cell loop
   double Da[ND], Db[ND], DTa[ND], DTb[ND]; // D[a][.], D[b][.], D[.][a], D[.][b]
@@ -1286,9 +1381,17 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     DTa[mm] = sD[mm * ND + a];
     DTb[mm] = sD[mm * ND + b];
   }
-  double* q_s = sq + wave * WL + cw * NQ2;
-  double* gr_s = sgr + wave * WL + cw * NQ2;
-  double* gs_s = sgs + wave * WL + cw * NQ2;
+  double* q_s = ssl + wave * (3 * WL) + cw * NQ2;
+  double* gr_s = q_s + WL;
+  double* gs_s = q_s + 2 * WL;
+#ifdef PMG_STREAM_NO_EARLY // measurement: the stream starts behind the barrier (the early loads of the first wavefronts
+                           // queue ahead of the gathers of the last ones on the same compute unit)
+  {
+    const unsigned g0 = gitem(0);
+    gfetch(0, g0, 0);
+    gfetch(1, g0, ND > 1 ? 1 : 0);
+  }
+#endif
   const uint16_t* slm = reinterpret_cast<const uint16_t*>(slm4);
 
   // Slots: layer k of an item lives in slot k & 1.  On entry to an item its layers 0 and 1 are in flight in slots 0
@@ -1297,21 +1400,26 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   // body serves the whole stream).
   for (int j = 0; j < nmy; ++j)
   {
+#ifdef PMG_STAMPS
+    if (j > 0)
+      PMG_STAMP(3); // start of the last item
+#endif
     const int it = wave + j * NG;
     const int slot = it * CW + cw;
     const int slotc = slot < K ? slot : K - 1;
-    const double2* gthis = gitem(j);
-    const double2* gnext = gitem(j + 1);
-    int l[ND];
+    const unsigned gthis = gitem(j), gnext = gitem(j + 1);
+    int l[ND]; // the column's positions in the patch list
 #pragma unroll
     for (int k = 0; k < ND; ++k)
       l[k] = slm[slotc * N + k * NQ2 + ab];
+    // kappa multiplies the cell's INPUT once (the operator is linear in it: same value to rounding) instead of every
+    // flux; nothing of it is held through the layer loop
     const double kap = skap[slotc];
     double u[ND], Aq[ND];
 #pragma unroll
     for (int k = 0; k < ND; ++k)
     {
-      u[k] = sx[l[k]];
+      u[k] = kap * sx[l[k]];
       Aq[k] = 0.0;
     }
 #pragma unroll
@@ -1329,7 +1437,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
         qt += Dg[k * ND + mm] * u[mm];                         // d/dz: registers, uniform table, :214-218
       }
       const double2 g01 = gq[s][0], g23 = gq[s][1], g45 = gq[s][2];
-      const double fr = g01.x * qr + g01.y * qs + g23.x * qt; // :233 (kappa: once per item, below)
+      const double fr = g01.x * qr + g01.y * qs + g23.x * qt; // :233 (kappa: in u, above)
       const double fs = g01.y * qr + g23.y * qs + g45.x * qt; // :234
       const double ft = g23.x * qr + g45.x * qs + g45.y * qt; // :235
       if (k + 2 < ND)
@@ -1350,21 +1458,25 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
       Aq[k] += acc;
       wave_fence();
     }
-    const double kc = (lane_ok && slot < nc) ? kap : 0.0; // lanes without a cell add an exact zero
+    const bool contributes = lane_ok && slot < nc; // lanes without a cell add an exact zero
 #pragma unroll
     for (int k = 0; k < ND; ++k)
-      atomicAdd(&sy[l[k]], kc * Aq[k]); // :270,277 -- in LDS (ds_add_f64)
+      atomicAdd(&sy[l[k]], contributes ? Aq[k] : 0.0); // :270,277 -- in LDS (ds_add_f64)
   }
   // ---- write back (plain stores; the accumulator started from the earlier colours' y)
   {
     // (the thread index made opaque here: otherwise the list addresses are computed ahead of the cell loop and
     // held -- or spilled -- through it)
+    PMG_STAMP(4); // cell loop done
     int tw = t;
     asm volatile("" : "+v"(tw));
     uint32_t mk[ITER];
     patch_list_reload<ITER, THREADS>(mk, pdofs + off, M, tw);
     lds_barrier();
+    PMG_STAMP(5); // behind the barrier that ends the accumulation
     patch_write_back<ITER, THREADS, NT>(mk, M, tw, sy, x, y, atomic_out);
+    PMG_STAMP(6); // stores issued
+    PMG_STAMP_FLUSH(Sh::NW);
   }
 }
 
@@ -1634,6 +1746,7 @@ namespace pmg
 // used by solvers.hip
 int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s);
 int laplacian_apply_zeroed(pmg_laplacian op, double* in, double* out, hipStream_t s);
+int laplacian_apply_ghosts_current(pmg_laplacian op, double* in, double* out, hipStream_t s);
 const double* laplacian_diag_inv(pmg_laplacian op) { return op->diag_inv; }
 pmg_layout laplacian_layout(pmg_laplacian op) { return op->layout; }
 long long laplacian_launches(pmg_laplacian op) { return op->applies; }
@@ -1688,7 +1801,8 @@ static bool zero_fills_output(pmg_laplacian op)
 bool laplacian_wants_zeroed_output(pmg_laplacian op) { return zero_fills_output(op); }
 
 // operator()(in, out), src/laplacian.hpp:462-482 + impl_operator :373-460
-static int apply_impl(pmg_laplacian op, double* in, double* out, bool out_is_zero, hipStream_t s)
+static int apply_impl(pmg_laplacian op, double* in, double* out, bool out_is_zero, hipStream_t s,
+                      bool exchange = true)
 {
   pmg_layout l = op->layout;
   const int nl = (int)op->launch_first.size();
@@ -1700,14 +1814,22 @@ static int apply_impl(pmg_laplacian op, double* in, double* out, bool out_is_zer
   if (op->n_bzero > 0 && !zero_all)
     zero_list_kernel<<<(op->n_bzero + 255) / 256 > 1024 ? 1024 : (op->n_bzero + 255) / 256, 256, 0, s>>>(
         op->n_bzero, op->bzero, out);
-  PMG_TRY(pmg_scatter_fwd_begin(l, in, (pmg_stream)s));          // :378
+  if (exchange)
+    PMG_TRY(pmg_scatter_fwd_begin(l, in, (pmg_stream)s));        // :378
   PMG_TRY(run_launches(op, in, out, 0, op->n_launch_l, s));      // :380-413 interior cells
-  PMG_TRY(pmg_scatter_fwd_end(l, in, (pmg_stream)s));            // :425
+  if (exchange)
+    PMG_TRY(pmg_scatter_fwd_end(l, in, (pmg_stream)s));          // :425
   PMG_TRY(run_launches(op, in, out, op->n_launch_l, nl, s));     // :429-455 boundary cells
   op->applies++;
   return PMG_OK;
 }
 int laplacian_apply(pmg_laplacian op, double* in, double* out, hipStream_t s) { return apply_impl(op, in, out, false, s); }
+// The ghost entries of `in` are current already (the caller's bookkeeping, solvers.hip local_correction): the same
+// application without its halo exchange.
+int laplacian_apply_ghosts_current(pmg_laplacian op, double* in, double* out, hipStream_t s)
+{
+  return apply_impl(op, in, out, false, s, false);
+}
 // `out` is zero over the whole layout already (only meaningful when laplacian_wants_zeroed_output)
 int laplacian_apply_zeroed(pmg_laplacian op, double* in, double* out, hipStream_t s)
 {
@@ -1995,6 +2117,16 @@ extern "C" int pmg_laplacian_destroy(pmg_laplacian op)
   delete op;
   return PMG_OK;
 }
+
+#ifdef PMG_STAMPS
+// diagnostic builds only (tools/stamp_apply.py); not part of the ABI
+extern "C" int pmg_debug_set_stamp_buffer(unsigned long long* buffer, int workgroups)
+{
+  PMG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buffer), &buffer, sizeof(buffer)));
+  PMG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_capacity), &workgroups, sizeof(workgroups)));
+  return PMG_OK;
+}
+#endif
 
 extern "C" int pmg_laplacian_degree(pmg_laplacian op) { return op ? op->P : -1; }
 

@@ -40,6 +40,7 @@ void launch_cheb_first(int n, double* x, double* r, double* z, const double* q, 
                        double c1, double c2, int x_final, hipStream_t s, double* clear_q = nullptr, int n_total = 0);
 bool laplacian_wants_zeroed_output(pmg_laplacian op);
 int laplacian_apply_zeroed(pmg_laplacian op, double* in, double* out, hipStream_t s);
+int laplacian_apply_ghosts_current(pmg_laplacian op, double* in, double* out, hipStream_t s);
 } // namespace pmg
 
 struct pmg_chebyshev_s
@@ -105,18 +106,23 @@ namespace pmg
 //                               one-step smoother, whose only kernel updates x and r together, returns false).
 int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n, double lmax, int max_iter,
                  double* x, const double* b, int need_r, bool x_zero, hipStream_t s, bool* split,
-                 const ApplyFn* A_zeroed, int n_total)
+                 const ApplyFn* A_zeroed, int n_total, bool track_ghosts, const ApplyFn* A_first)
 {
   if (split)
     *split = false;
   double* const clear_q = A_zeroed ? w.q : nullptr; // the vector kernels leave w.q zero for the next application
   const ApplyFn& An = A_zeroed ? *A_zeroed : A;    // ... which then needs no zero-fill
   const double c0 = 4.0 / (3.0 * lmax);
+  const int ng = track_ghosts && n_total > n ? n_total - n : 0; // ghost entries of x kept current (see common.hpp)
   if (x_zero)
+  {
     launch_cheb_init(n, w.r, w.z, b, nullptr, dinv, c0, s, clear_q, n_total);
+    if (ng > 0)
+      launch_zero(ng, x + n, s);
+  }
   else
   {
-    PMG_TRY(A(x, w.q));                                                     // :56
+    PMG_TRY(A_first ? (*A_first)(x, w.q) : A(x, w.q));                      // :56 (refreshes the ghosts of x)
     launch_cheb_init(n, w.r, w.z, b, w.q, dinv, c0, s, clear_q, n_total); // :57,67-68
   }
   // x absorbs the correction z_{i+1} in the step kernel that computes it (the first step adds z_1 and z_2), so
@@ -136,6 +142,8 @@ int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n,
       break;
     }
     PMG_TRY(An(w.z, w.q)); // :76
+    if (ng > 0)             // the ghosts of z are current now: the iterate's ghosts absorb them
+      launch_add(ng, x + n, w.z + n, s);
     if (last) // need_r: the new z would not be used, only x and r are (:73,77)
     {
       if (max_iter == 1)
@@ -182,8 +190,10 @@ int alloc_vec(pmg_layout l, double** p)
 }
 
 // src/chebyshev.hpp:46-91 on the operator `A` (see cheb_iterate)
+// track_ghosts / x_ghosts_current: the exchange bookkeeping of the V-cycle, see cheb_iterate (common.hpp)
 int cheb_solve(pmg_chebyshev sm, pmg_laplacian A, double* x, const double* b, int need_r,
-               bool x_zero, hipStream_t s, bool* split = nullptr)
+               bool x_zero, hipStream_t s, bool* split = nullptr, bool track_ghosts = false,
+               bool x_ghosts_current = false)
 {
   pmg_layout l = sm->layout;
   PMG_REQUIRE(laplacian_layout(A) == l, "Chebyshev: operator and smoother layouts differ");
@@ -191,8 +201,24 @@ int cheb_solve(pmg_chebyshev sm, pmg_laplacian A, double* x, const double* b, in
   // eig_range[0] is unused (src/chebyshev.hpp:51); no per-call D2D copy of the diagonal (:53)
   const ApplyFn apply = [A, s](double* in, double* out) { return laplacian_apply(A, in, out, s); };
   const ApplyFn apply_zeroed = [A, s](double* in, double* out) { return laplacian_apply_zeroed(A, in, out, s); };
+  const ApplyFn apply_local = [A, s](double* in, double* out) { return laplacian_apply_ghosts_current(A, in, out, s); };
   return cheb_iterate(w, apply, laplacian_diag_inv(A), l->size_local, sm->eig_max, sm->max_iter, x, b, need_r, x_zero,
-                      s, split, laplacian_wants_zeroed_output(A) ? &apply_zeroed : nullptr, l->total());
+                      s, split, laplacian_wants_zeroed_output(A) ? &apply_zeroed : nullptr, l->total(), track_ghosts,
+                      x_ghosts_current ? &apply_local : nullptr);
+}
+
+// Exchange bookkeeping on several ranks (round 4).  u_i leaves its pre-smooth with current ghosts (the smoother adds
+// the ghosts of every applied correction, cheb_iterate); the patch form of the prolongation computes the correction on
+// EVERY local cell, ghost cells included, from the coarse ghosts it has just received, and adds it to every patch dof it
+// writes first -- ghost dofs too: u_i + P u_{i-1} therefore has current ghosts without an exchange of its own, and the
+// first application of the post-smooth runs without one (19 -> 17 exchanges per cycle of three levels with k = 3).
+// Values at a ghost dof are computed from another cell than on the owner: equal to rounding, not bit for bit.
+bool local_correction(pmg_multigrid mg, int level)
+{
+  if (const char* e = std::getenv("PMG_LOCAL_CORRECTION")) // tests / measurements: 0 = an exchange per application
+    if (e[0] == '0')
+      return false;
+  return level > 0 && mg->layouts[level]->num_ghosts > 0 && interp_is_patched(mg->interps[level - 1]);
 }
 
 // src/pmg.hpp:56-155 (lean form, see the file header)
@@ -216,9 +242,10 @@ int mg_apply(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStr
     bool split = false;
     {
       Range rg("pmg:pre_smooth");
+      // (several ranks: the iterate leaves the pre-smooth with current ghosts, see `local_correction` below)
       PMG_TRY(cheb_solve(mg->smoothers[i], mg->ops[i], mg->u[i], bi,
                          interp_restricts_difference(mg->interps[i - 1]) ? ResidualSplit : ResidualUpdated, zero, s,
-                         &split)); // :83-87
+                         &split, local_correction(mg, i))); // :83-87
     }
     Range rg("pmg:restrict");
     if (split) // the residual r - q is formed by the restriction's gather
@@ -267,7 +294,9 @@ int mg_apply(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStr
     }
     Range rg("pmg:post_smooth");
     const double* bi = (i + 1 == L - 1) ? rhs : mg->b[i + 1];
-    PMG_TRY(cheb_solve(mg->smoothers[i + 1], mg->ops[i + 1], mg->u[i + 1], bi, ResidualNone, false, s)); // :138
+    // with local_correction the ghosts of u are current here: the post-smooth's first application needs no exchange
+    PMG_TRY(cheb_solve(mg->smoothers[i + 1], mg->ops[i + 1], mg->u[i + 1], bi, ResidualNone, false, s, nullptr, false,
+                       local_correction(mg, i + 1))); // :138
   }
   for (int i = 0; i < L; ++i)
     mg->counts[i] = (int)(laplacian_launches(mg->ops[i]) - before[i]);

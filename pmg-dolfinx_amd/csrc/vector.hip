@@ -806,9 +806,13 @@ extern "C" int pmg_layout_set_allreduce_max(pmg_layout l, pmg_allreduce_fn allre
 }
 
 // src/vector.hpp:186-207
+// forward scatters issued on the layout since its creation (a captured cycle counts once, at capture)
+extern "C" long long pmg_layout_forward_scatters(pmg_layout l) { return l ? l->fwd_scatters : -1; }
+
 extern "C" int pmg_scatter_fwd_begin(pmg_layout l, const double* x, pmg_stream stream)
 {
   PMG_REQUIRE(l && x, "pmg_scatter_fwd_begin: NULL argument");
+  l->fwd_scatters++;
   if (l->win)
     return window_exchange_begin(l, false, x, S(stream));
   if (!l->comm && !l->exchange)

@@ -365,6 +365,10 @@ class Layout:
     def total(self):
         return self.size_local + self.num_ghosts
 
+    def forward_scatters(self) -> int:
+        """Forward scatters issued on this layout so far (``pmg_layout_forward_scatters``)."""
+        return int(call("pmg_layout_forward_scatters", self.handle))
+
     def __del__(self):
         try:
             if self._handle is not None:

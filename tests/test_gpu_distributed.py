@@ -135,6 +135,14 @@ def _rank_checks(pm, rank, world, n, dims, orders, comm=None):
                      abs(rn - mg.rnorm) / mg.rnorm))
     out["vcycle_err"] = verr
     out["eig_ref"] = eigs
+    # exchanges of one cycle (round 4): an operator application, a prolongation and a restriction each refresh the
+    # ghosts of their input -- except the first application of every post-smooth, whose input u + P u_c has current
+    # ghosts by construction (solvers.hip, local_correction).  Three levels, k = 3: 7 + 6 + 2 + 4 - 2 = 17.
+    before = sum(l.forward_scatters() for l in H.layouts)
+    H.mg.apply(H.rhs[-1], xv)
+    L = len(orders)
+    expect = (2 * k + 1) + 2 * k * (L - 2) + (k - 1) + 2 * (L - 1) - (L - 1) if L > 1 else k
+    out["exchanges_per_cycle"] = (sum(l.forward_scatters() for l in H.layouts) - before, expect)
     # the coarsest level solved by CG + AMG (each rank's hierarchy on its own block: a block preconditioner
     # for the distributed Krylov solve) against the oracle's cycle with an exact coarse solve
     import scipy.sparse.linalg as spla
@@ -204,6 +212,7 @@ def _assert_rank_results(res):
             assert abs(got[1] - ref[1]) < 1e-8 * ref[1]
         for e, rn in out["vcycle_err"]:
             assert e < 1e-10 and rn < 1e-8
+        assert out["exchanges_per_cycle"][0] == out["exchanges_per_cycle"][1], out["exchanges_per_cycle"]
         assert max(out["amg_vcycle_err"]) < 1e-7, out["amg_vcycle_err"]
         assert out["rep_err"] < 1e-7 and max(out["rep_vcycle_err"]) < 1e-5, (out["rep_err"], out["rep_vcycle_err"])
     # the replicated hierarchy is the same on every rank, and it is the single-rank hierarchy

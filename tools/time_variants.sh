@@ -1,10 +1,13 @@
 #!/bin/bash
-# Time the operator apply of every variant library in tools/abl (tools/build_variant.sh) for the P:n pairs given,
-# on the GPU box:   tools/time_variants.sh 4:64 6:43 8:32
+# Time the operator apply of variant libraries in tools/abl (tools/build_variant.sh) for the P:n pairs given, on the GPU
+# box:   tools/time_variants.sh 4:64 6:43 8:32        (all libraries)
+#        LIBS="wb stream4" tools/time_variants.sh 4:64   (only these)
 cd "$(dirname "$0")/.."
-for lib in tools/abl/lib_*.so; do
-  for Pn in "$@"; do
+libs=${LIBS:-$(ls tools/abl/lib_*.so | sed 's|tools/abl/lib_||; s|\.so||')}
+for Pn in "$@"; do
+  for l in $libs; do
+    lib=tools/abl/lib_$l.so
     PMG_AMD_LIB_ALLOW_MISSING=1 PMG_AMD_LIB=$PWD/$lib timeout -k 10 120 python tools/time_apply.py ${Pn%%:*} ${Pn##*:} 2>&1 | grep kernel \
-      | sed "s|lib=[^ ]*|lib=$(basename $lib .so)|"
+      | sed "s|lib=[^ ]*|lib=$l|"
   done
 done
