@@ -188,8 +188,9 @@ def parse_args(argv=None):
                     help="N > 1: skip the strong-scaled config-3 block AND with it the numeric gate against the C oracle "
                          "(the line then says parity 'unverified')")
     ap.add_argument("--corrupt-halo", action="store_true",
-                    help="TEST of the gate: the last rank's finest-level halo plan of the strong-scaling block gets two "
-                         "ghost slots swapped; every route must then fail the gate (value null, exit code 1)")
+                    help="TEST of the gate: the last rank's finest-level halo plan of the strong-scaling block gets the "
+                         "middle half of its ghost slots reversed; every route must then fail the gate (value null, exit "
+                         "code 1)")
     ap.add_argument("--graph-exchange", action="store_true",
                     help="N > 1 with the library's communicator: additionally time the cycles replayed as a hipGraph "
                          "with the halo exchange captured on the compute stream (one hipGraphLaunch instead of ~115 us "
@@ -391,6 +392,8 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warm-up, then EXACTLY K timed V-cycles (stationary iteration, examples/pmg/main.cpp:362-367) ----
+    # `value` is the EAGER cycle (stream-ordered launches) on every route; the replayed cycle is reported next to it
+    H.mg.set_graph(False)
     for _ in range(args.warmup):
         H.mg.apply(b, x)
     sync_all()
@@ -618,9 +621,12 @@ def main():
                 continue
 
             def hook(lv):
-                if args.corrupt_halo and rank == world - 1 and lv.P == P and len(lv.recv_indices) >= 2:
+                if args.corrupt_halo and rank == world - 1 and lv.P == P and len(lv.recv_indices) >= 8:
+                    # the middle half of the ghost slots in reverse order (the first slots of a list are Dirichlet
+                    # dofs of the domain boundary, whose values never enter the operator)
+                    ng_ = len(lv.recv_indices)
                     lv.recv_indices = lv.recv_indices.copy()
-                    lv.recv_indices[[0, 1]] = lv.recv_indices[[1, 0]]  # two ghost slots swapped
+                    lv.recv_indices[ng_ // 4: 3 * ng_ // 4] = lv.recv_indices[ng_ // 4: 3 * ng_ // 4][::-1].copy()
 
             Hs = pm.PoissonHierarchy((args.n,) * 3, orders, kappa=2.0, cheb_its=args.cheb, proc_dims=dims, rank=rank,
                                      size=world, comm=rcomm, level_hook=hook)
@@ -669,8 +675,7 @@ def main():
             # the route's first GATE_CYCLES cycles from x0 = 0, as it will be timed (eager or replayed)
             xs_ = Hs.new_vector()
             xs_.set(0.0)
-            if captured:
-                Hs.mg.set_graph(True)
+            Hs.mg.set_graph(bool(captured))  # explicit: the library's default may be either
             rns_g = [Hs.mg.apply(bs_, xs_, verbose=True) for _ in range(GATE_CYCLES)]
             xg = gather_global(xs_, lvs, nd_s)
             passed = torch.tensor([0], device=ctl)
@@ -694,8 +699,7 @@ def main():
                 entry.update(value=None, parity_failed=True)
                 parity_failures.append(f"strong-scaling route {name}: the {world}-rank cycle does not reproduce the "
                                        f"single-domain C oracle ({entry.get('gate')})")
-            if captured:
-                Hs.mg.set_graph(False)
+            Hs.mg.set_graph(None)
             res["routes"][name] = entry
             res.update(fine_dofs_global=nd_s, local_dofs=[lv.size_local for lv in Hs.levels],
                        ghosts=[lv.num_ghosts for lv in Hs.levels])

@@ -522,16 +522,21 @@ int pmg_multigrid_apply(pmg_multigrid mg, const double* rhs, double* y, double* 
  * correction), the prolongation computes the coarse correction on the ghost cells too, so u + P u_c has current ghosts
  * without an exchange of its own.  Three levels, Chebyshev(3): 17 exchanges per cycle instead of 19.
  * PMG_LOCAL_CORRECTION=0 in the environment restores one exchange per application. */
-/* hipGraph replay of the cycle.  With enable != 0, pmg_multigrid_apply (and the V-cycle preconditioner
- * inside pmg_cg_solve) captures the cycle's ~120 launches into a graph the first time it sees a
- * (rhs, y) pair and replays it afterwards with one hipGraphLaunch on the caller's stream: same
- * kernels, same order, same results.  Captured only when nothing in the cycle needs the host: no
- * exchange callbacks, no Krylov / callback coarse solver, no in-situ profiling; otherwise the call runs
- * eagerly as before.  Layouts with a pmg_comm ARE captured: the grouped send / receive of every halo
- * exchange is recorded on the capture stream, so a replayed cycle costs the host one launch instead of
- * ~115 us per exchange (and gives up the overlap of the exchange with the interior cells).  A change of a smoother's iteration count or bound, of a geometry mode or of the
- * coarse solver is noticed (new graph); calling this function again drops the cached graphs (do that
- * after replacing an operator's diagonal or any caller-owned array in place). */
+/* hipGraph replay of the cycle.  enable > 0: pmg_multigrid_apply (and the V-cycle preconditioner inside
+ * pmg_cg_solve) captures the cycle's ~120 launches into a graph the first time it sees a (rhs, y) pair and replays it
+ * afterwards with one hipGraphLaunch on the caller's stream: same kernels, same order, same results.  enable == 0:
+ * never.  enable < 0, the default: automatic -- on one rank eager (the launches run ahead of the GPU anyway: a replay
+ * buys nothing), on several ranks replayed wherever the capture holds nothing but kernels (every exchange through halo
+ * windows, the cycle's reductions through a communicator made of windows), because an eager exchange costs the host
+ * more than the GPU; a cycle whose exchanges are RCCL calls is replayed on request only (enable > 0, or
+ * PMG_GRAPH_AUTO=rccl in the environment; PMG_GRAPH_AUTO=0 turns the automatic choice off): that capture has run on
+ * one GPU, never between two.
+ * Captured only when nothing in the cycle needs the host: no exchange callbacks, no Krylov / callback coarse solver, no
+ * in-situ profiling; otherwise the call runs eagerly as before.  Layouts with a pmg_comm ARE captured: the grouped
+ * send / receive of every halo exchange is recorded into the graph (on a HIP >= 7.2 runtime as a parallel branch that
+ * keeps its overlap with the interior cells, pmg_comm_capture_overlaps).  A change of a smoother's iteration count or
+ * bound, of a geometry mode or of the coarse solver is noticed (new graph); calling this function again drops the
+ * cached graphs (do that after replacing an operator's diagonal or any caller-owned array in place). */
 int pmg_multigrid_set_graph(pmg_multigrid mg, int enable);
 long long pmg_multigrid_graph_replays(pmg_multigrid mg);
 /* Number of stiffness-kernel launches issued by the last pmg_multigrid_apply,

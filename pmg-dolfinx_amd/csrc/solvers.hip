@@ -13,6 +13,8 @@
 // last A z of a post-smooth changes neither x nor anything that is read again.
 #include "common.hpp"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -89,7 +91,7 @@ struct pmg_multigrid_s
     hipGraphExec_t exec;
     std::vector<int> counts;
   };
-  bool graph_enabled = false;
+  int graph_mode = -1; // pmg_multigrid_set_graph: 1 replay when capturable, 0 never, -1 (default) automatic: use_graph()
   std::vector<GraphEntry> graphs;
   hipStream_t capture_stream = nullptr;
   long long graph_replays = 0;
@@ -177,6 +179,7 @@ int cheb_iterate(const ChebWork& w, const ApplyFn& A, const double* dinv, int n,
 namespace
 {
 int mg_apply_graph(pmg_multigrid mg, const double* rhs, double* y, bool y_zero, hipStream_t s, bool* done);
+bool use_graph(pmg_multigrid mg);
 // every captured cycle holds the device pointers of the objects it was captured with: any change of
 // the multigrid's parts invalidates all of them
 void drop_graphs(pmg_multigrid mg);
@@ -507,7 +510,7 @@ extern "C" int pmg_cg_solve(pmg_cg cg, pmg_laplacian A, double* x, const double*
   const PrecondFn vcycle = [precond, s](double* z, const double* r) -> int
   {
     bool done = false;
-    if (precond->graph_enabled)
+    if (use_graph(precond))
       PMG_TRY(mg_apply_graph(precond, r, z, true, s, &done));
     return done ? PMG_OK : mg_apply(precond, r, z, true, s);
   };
@@ -694,6 +697,40 @@ void drop_graphs(pmg_multigrid mg)
 
 // What a captured cycle depends on besides its two vectors; -1: this configuration cannot be
 // captured (a host synchronisation or a host callback inside the cycle, in-situ timing events)
+// Is the cycle replayed as a hipGraph?  Explicitly on / off (pmg_multigrid_set_graph), or by default: on one rank the
+// launches are issued ahead of the GPU anyway and a replay buys nothing (5.40 against 5.42 ms at config 2); on several
+// ranks an eager exchange costs the host more than the GPU (profiles/exchange_overhead_r02.txt; four ranks on one GPU,
+// round 4: 8.4 ms eager against 6.3 ms replayed at 64^3 in total), so the cycle is captured BY DEFAULT wherever the
+// capture holds nothing but kernels -- every exchange through halo windows, every reduction of the cycle through a
+// communicator made of windows.  A cycle whose exchanges are RCCL calls is captured on request only: that capture
+// has run on one GPU (a rank as its own partner), never between two, and a runtime that misbehaves there would take
+// the caller's run down rather than fail a check (PMG_GRAPH_AUTO=rccl includes it in the default, =0 turns the
+// default off).
+bool use_graph(pmg_multigrid mg)
+{
+  if (mg->graph_mode >= 0)
+    return mg->graph_mode == 1;
+  const char* e = std::getenv("PMG_GRAPH_AUTO");
+  if (e && e[0] == '0')
+    return false;
+  const bool rccl_too = e && std::string(e) == "rccl";
+  bool several = false;
+  for (int i = 0; i < mg->L; ++i)
+  {
+    pmg_layout l = mg->layouts[i];
+    if (!l->multi_rank() && !l->win)
+      continue;
+    several = true;
+    if (l->exchange && !l->comm && !l->win)
+      return false; // callbacks: host code in the cycle
+    if (!l->win && !rccl_too)
+      return false; // grouped ncclSend / ncclRecv in the capture
+    if (mg->coarse_amg && i == 0 && l->comm && !l->comm->wcomm && !rccl_too)
+      return false; // the replicated coarse solve's ncclAllReduce in the capture
+  }
+  return several;
+}
+
 long long capture_config(pmg_multigrid mg)
 {
   uint64_t h = 1469598103934665603ull;
@@ -793,7 +830,7 @@ extern "C" int pmg_multigrid_set_graph(pmg_multigrid mg, int enable)
 {
   PMG_REQUIRE(mg, "pmg_multigrid_set_graph: NULL argument");
   drop_graphs(mg);
-  mg->graph_enabled = enable != 0;
+  mg->graph_mode = enable < 0 ? -1 : (enable != 0 ? 1 : 0);
   return PMG_OK;
 }
 
@@ -805,7 +842,7 @@ extern "C" int pmg_multigrid_apply(pmg_multigrid mg, const double* rhs, double* 
   PMG_REQUIRE(mg && rhs && y, "pmg_multigrid_apply: NULL argument");
   hipStream_t s = S(stream);
   bool done = false;
-  if (mg->graph_enabled)
+  if (use_graph(mg))
     PMG_TRY(mg_apply_graph(mg, rhs, y, false, s, &done));
   if (!done)
     PMG_TRY(mg_apply(mg, rhs, y, false, s));

@@ -94,10 +94,11 @@ class MultigridPreconditioner:
         call("pmg_multigrid_apply", self._handle, ptr(x.data), ptr(y.data), None, current_stream())
         return None
 
-    def set_graph(self, enable: bool = True):
+    def set_graph(self, enable=True):
         """Replay the cycle as a hipGraph (captured on first use per (rhs, y) pair) where nothing in it
-        needs the host; see ``pmg_multigrid_set_graph``."""
-        call("pmg_multigrid_set_graph", self._handle, 1 if enable else 0)
+        needs the host: ``True`` / ``False``, or ``None`` for the library's default (eager on one rank; replayed
+        on several ranks when the capture holds nothing but kernels); see ``pmg_multigrid_set_graph``."""
+        call("pmg_multigrid_set_graph", self._handle, -1 if enable is None else (1 if enable else 0))
 
     def graph_replays(self) -> int:
         return call("pmg_multigrid_graph_replays", self._handle)
