@@ -193,6 +193,14 @@ struct TransferArgs
   const double* M1;
 };
 
+// Round 4, from the in-kernel stamps of the operator (profiles/kernel_tuning_r04.md): under load every DEPENDENT global
+// load costs ~2 us, also when it hits in L2, so what a workgroup needs at its end is requested at its start --
+// the prolongation re-reads nothing behind its contraction (the fine dof list, and with `add` the fine values it
+// adds to, are in registers by then), the restriction has its coarse list in registers.  Fine cells of at most 32
+// dofs (degree 2) are taken TWO per wavefront pass, one per half-wavefront: 54 of 64 lanes busy instead of 27.
+constexpr int transfer_cpw(int ndf) { return ndf * ndf * ndf <= 32 ? 2 : 1; } // cells per wavefront pass
+constexpr int TRANSFER_LIST_ITER = 6; // list entries per thread held in registers (6 x 512 threads >= any patch list)
+
 template <int NDC, int NDF>
 __global__ void prolong_patch_kernel(TransferArgs A, const double* __restrict__ coarse,
                                      double* __restrict__ fine, int add)
@@ -200,90 +208,110 @@ __global__ void prolong_patch_kernel(TransferArgs A, const double* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int ndc = NDC, ndf = NDF, Nc = ndc * ndc * ndc, Nf = ndf * ndf * ndf;
   constexpr int n1 = ndf * ndc * ndc, n2 = ndf * ndf * ndc;
+  constexpr int CPW = transfer_cpw(NDF), HL = 64 / CPW; // cells per wavefront pass, lanes per cell
+  constexpr int IT = TRANSFER_LIST_ITER;
   double* sM = smem;                  // [ndf*ndc]
   double* sc = sM + ndf * ndc;        // [max_mc] coarse values of the patch
   double* sf = sc + A.max_mc;         // [max_mf] fine values of the patch
-  double* scratch = sf + A.max_mf;    // per wave: uc[Nc] t1[n1] t2[n2]
-  const int p = A.first + blockIdx.x, t = threadIdx.x;
+  double* scratch = sf + A.max_mf;    // per wave and cell of the pass: uc[Nc] t1[n1] t2[n2]
+  const int p = A.first + blockIdx.x, t = threadIdx.x, nthr = blockDim.x;
   const int off = A.poff[p], Mf = A.poff[p + 1] - off;
   const int coff = A.cpoff[p], Mc = A.cpoff[p + 1] - coff;
   const int nc = A.pncell[p];
-  for (int i = t; i < ndf * ndc; i += blockDim.x)
+  // what the write-back needs, requested first: the fine list ...
+  uint32_t m[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k)
+  {
+    const int i = t + k * nthr;
+    m[k] = A.pdofs[off + (i < Mf ? i : Mf - 1)];
+  }
+  for (int i = t; i < ndf * ndc; i += nthr)
     sM[i] = A.M1[i];
-  for (int i = t; i < Mc; i += blockDim.x)
+  for (int i = t; i < Mc; i += nthr)
     sc[i] = coarse[A.cpdofs[coff + i] & PD_MASK];
+  // ... and the values the correction is added to (they arrive under the contraction)
+  double v[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k)
+    v[k] = !add ? 0.0 : A.nt ? __builtin_nontemporal_load(fine + (m[k] & PD_MASK)) : fine[m[k] & PD_MASK];
   tbarrier();
-  const int wave = t >> 6, lane = t & 63, nw = blockDim.x >> 6;
-  double* uc = scratch + (size_t)wave * (Nc + n1 + n2);
+  const int wave = t >> 6, lane = t & 63, nw = nthr >> 6;
+  const int half = lane / HL, ll = lane - half * HL; // the lane's cell of the pass, its lane inside the cell
+  double* uc = scratch + (size_t)(wave * CPW + half) * (Nc + n1 + n2);
   double* t1 = uc + Nc;
   double* t2 = t1 + n1;
   const uint16_t* cl = A.clmaps + (size_t)A.clmap_id[p] * A.K * Nc;
   const uint16_t* fl = A.lmaps + (size_t)A.lmap_id[p] * A.K * Nf;
   // the (cell, local dof) -> patch position tables of the NEXT cell are fetched while the
   // current one is computed, so the cell loop itself touches only LDS
-  constexpr int FP = (Nf + 63) / 64, CP = (Nc + 63) / 64;
+  constexpr int FP = (Nf + HL - 1) / HL, CP = (Nc + HL - 1) / HL;
   int fcur[FP], ccur[CP], fnxt[FP], cnxt[CP];
   auto fetch = [&](int slot, int* fi, int* ci) {
+    const int sl = slot < nc ? slot : nc - 1; // (a half-wavefront without a cell re-reads the last one's tables)
 #pragma unroll
     for (int j = 0; j < CP; ++j)
     {
-      const int o = lane + 64 * j;
-      ci[j] = cl[(size_t)slot * Nc + (o < Nc ? o : Nc - 1)];
+      const int o = ll + HL * j;
+      ci[j] = cl[(size_t)sl * Nc + (o < Nc ? o : Nc - 1)];
     }
 #pragma unroll
     for (int j = 0; j < FP; ++j)
     {
-      const int o = lane + 64 * j, oc = o < Nf ? o : Nf - 1;
+      const int o = ll + HL * j, oc = o < Nf ? o : Nf - 1;
       const int a = oc / (ndf * ndf), r = oc - a * ndf * ndf, b = r / ndf, c = r - b * ndf;
-      fi[j] = fl[(size_t)slot * Nf + ftab(ndf, a, b, c)];
+      fi[j] = fl[(size_t)sl * Nf + ftab(ndf, a, b, c)];
     }
   };
-  if (wave < nc)
-    fetch(wave, fcur, ccur);
-  for (int slot = wave; slot < nc; slot += nw)
+  if (wave * CPW < nc)
+    fetch(wave * CPW + half, fcur, ccur);
+  for (int slot0 = wave * CPW; slot0 < nc; slot0 += nw * CPW)
   {
-    if (slot + nw < nc)
-      fetch(slot + nw, fnxt, cnxt);
+    const int slot = slot0 + half;
+    const bool mine = slot < nc;
+    if (slot0 + nw * CPW < nc)
+      fetch(slot + nw * CPW, fnxt, cnxt);
 #pragma unroll
     for (int j = 0; j < CP; ++j)
     {
-      const int o = lane + 64 * j;
+      const int o = ll + HL * j;
       if (o < Nc)
         uc[o] = sc[ccur[j]];
     }
     tfence();
-    for (int o = lane; o < n1; o += 64) // (a, j, k): sum over i
+    for (int o = ll; o < n1; o += HL) // (a, j, k): sum over i
     {
       const int a = o / (ndc * ndc), jk = o - a * ndc * ndc;
-      double v = 0.0;
+      double w = 0.0;
       #pragma unroll
       for (int i = 0; i < ndc; ++i)
-        v += sM[a * ndc + i] * uc[i * ndc * ndc + jk];
-      t1[o] = v;
+        w += sM[a * ndc + i] * uc[i * ndc * ndc + jk];
+      t1[o] = w;
     }
     tfence();
-    for (int o = lane; o < n2; o += 64) // (a, b, k): sum over j
+    for (int o = ll; o < n2; o += HL) // (a, b, k): sum over j
     {
       const int a = o / (ndf * ndc), r = o - a * ndf * ndc, b = r / ndc, k = r - b * ndc;
-      double v = 0.0;
+      double w = 0.0;
       #pragma unroll
       for (int j = 0; j < ndc; ++j)
-        v += sM[b * ndc + j] * t1[(a * ndc + j) * ndc + k];
-      t2[o] = v;
+        w += sM[b * ndc + j] * t1[(a * ndc + j) * ndc + k];
+      t2[o] = w;
     }
     tfence();
 #pragma unroll
     for (int jj = 0; jj < FP; ++jj) // (a, b, c): sum over k
     {
-      const int o = lane + 64 * jj;
+      const int o = ll + HL * jj;
       if (o < Nf)
       {
         const int a = o / (ndf * ndf), r = o - a * ndf * ndf, b = r / ndf, c = r - b * ndf;
-        double v = 0.0;
+        double w = 0.0;
         #pragma unroll
         for (int k = 0; k < ndc; ++k)
-          v += sM[c * ndc + k] * t2[(a * ndf + b) * ndc + k];
-        sf[fcur[jj]] = v; // shared dofs: identical values
+          w += sM[c * ndc + k] * t2[(a * ndf + b) * ndc + k];
+        if (mine)
+          sf[fcur[jj]] = w; // shared dofs: identical values
       }
     }
     tfence();
@@ -295,26 +323,18 @@ __global__ void prolong_patch_kernel(TransferArgs A, const double* __restrict__ 
       fcur[j] = fnxt[j];
   }
   tbarrier();
-  for (int i0 = t; i0 < Mf; i0 += 4 * blockDim.x)
+#pragma unroll
+  for (int k = 0; k < IT; ++k)
   {
-    uint32_t m[4];
-    double v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-    {
-      const int i = i0 + k * blockDim.x;
-      m[k] = A.pdofs[off + (i < Mf ? i : Mf - 1)];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      v[k] = !add ? 0.0 : A.nt ? __builtin_nontemporal_load(fine + (m[k] & PD_MASK)) : fine[m[k] & PD_MASK];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-    {
-      const int i = i0 + k * blockDim.x;
-      if (i < Mf && !(m[k] & PD_ACC)) // this patch is the first (only) writer of the dof
-        fine[m[k] & PD_MASK] = v[k] + sf[i]; // src/interpolate.hpp:42 (+ src/pmg.hpp:129 when add)
-    }
+    const int i = t + k * nthr;
+    if (i < Mf && !(m[k] & PD_ACC)) // this patch is the first (only) writer of the dof
+      fine[m[k] & PD_MASK] = v[k] + sf[i]; // src/interpolate.hpp:42 (+ src/pmg.hpp:129 when add)
+  }
+  for (int i = t + IT * nthr; i < Mf; i += nthr) // (lists longer than the registers hold: few threads per workgroup)
+  {
+    const uint32_t mm = A.pdofs[off + i];
+    if (!(mm & PD_ACC))
+      fine[mm & PD_MASK] = (add ? fine[mm & PD_MASK] : 0.0) + sf[i];
   }
 }
 
@@ -326,19 +346,23 @@ __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int ndc = NDC, ndf = NDF, Nc = ndc * ndc * ndc, Nf = ndf * ndf * ndf;
   constexpr int n1 = ndf * ndc * ndc, n2 = ndf * ndf * ndc;
+  constexpr int CPW = transfer_cpw(NDF), HL = 64 / CPW;
   double* sM = smem;
   double* sc = sM + ndf * ndc;     // [max_mc] coarse accumulators
   double* sf = sc + A.max_mc;      // [max_mf] weighted fine values
-  double* scratch = sf + A.max_mf; // per wave: w[Nf] t2[n2] t1[n1]
-  const int p = A.first + blockIdx.x, t = threadIdx.x;
+  double* scratch = sf + A.max_mf; // per wave and cell of the pass: w[Nf] t2[n2] t1[n1]
+  const int p = A.first + blockIdx.x, t = threadIdx.x, nthr = blockDim.x;
   const int off = A.poff[p], Mf = A.poff[p + 1] - off;
   const int coff = A.cpoff[p], Mc = A.cpoff[p + 1] - coff;
   const int nc = A.pncell[p];
-  for (int i = t; i < ndf * ndc; i += blockDim.x)
+  // the coarse list, for the write-back at the end (one entry per thread: coarse patches are small; longer lists
+  // fall back to re-reading)
+  const uint32_t cm = A.cpdofs[coff + (t < Mc ? t : Mc - 1)];
+  for (int i = t; i < ndf * ndc; i += nthr)
     sM[i] = A.M1[i];
   // four independent (index -> value) load chains per thread and pass; clamped indices
   // keep every load unconditional
-  for (int i0 = t; i0 < Mf; i0 += 4 * blockDim.x)
+  for (int i0 = t; i0 < Mf; i0 += 4 * nthr)
   {
     uint32_t m[4];
     uint8_t mu[4];
@@ -346,7 +370,7 @@ __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
-      const int i = i0 + k * blockDim.x;
+      const int i = i0 + k * nthr;
       const int ic = off + (i < Mf ? i : Mf - 1);
       m[k] = A.pdofs[ic];
       mu[k] = A.pmult[ic];
@@ -363,55 +387,65 @@ __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__
 #pragma unroll
     for (int k = 0; k < 4; ++k)
     {
-      const int i = i0 + k * blockDim.x;
+      const int i = i0 + k * nthr;
       if (i < Mf)
         sf[i] = v[k] / (double)mu[k]; // src/interpolate.hpp:81-82
     }
   }
-  for (int i = t; i < Mc; i += blockDim.x)
   {
-    const uint32_t m = A.cpdofs[coff + i];
-    sc[i] = (!atomic_out && (m & PD_ACC)) ? coarse[m & PD_MASK] : 0.0; // onto the earlier colours
+    // onto the earlier colours (coloured write-back only)
+    const double c0 = (!atomic_out && (cm & PD_ACC)) ? coarse[cm & PD_MASK] : 0.0;
+    if (t < Mc)
+      sc[t] = c0;
+    for (int i = t + nthr; i < Mc; i += nthr)
+    {
+      const uint32_t mm = A.cpdofs[coff + i];
+      sc[i] = (!atomic_out && (mm & PD_ACC)) ? coarse[mm & PD_MASK] : 0.0;
+    }
   }
   tbarrier();
-  const int wave = t >> 6, lane = t & 63, nw = blockDim.x >> 6;
-  double* w = scratch + (size_t)wave * (Nf + n1 + n2);
+  const int wave = t >> 6, lane = t & 63, nw = nthr >> 6;
+  const int half = lane / HL, ll = lane - half * HL;
+  double* w = scratch + (size_t)(wave * CPW + half) * (Nf + n1 + n2);
   double* t2 = w + Nf;
   double* t1 = t2 + n2;
   const uint16_t* cl = A.clmaps + (size_t)A.clmap_id[p] * A.K * Nc;
   const uint16_t* fl = A.lmaps + (size_t)A.lmap_id[p] * A.K * Nf;
-  constexpr int FP = (Nf + 63) / 64, CP = (Nc + 63) / 64;
+  constexpr int FP = (Nf + HL - 1) / HL, CP = (Nc + HL - 1) / HL;
   int fcur[FP], ccur[CP], fnxt[FP], cnxt[CP]; // position tables, fetched one cell ahead (see prolong_patch_kernel)
   auto fetch = [&](int slot, int* fi, int* ci) {
+    const int sl = slot < nc ? slot : nc - 1;
 #pragma unroll
     for (int j = 0; j < CP; ++j)
     {
-      const int o = lane + 64 * j;
-      ci[j] = cl[(size_t)slot * Nc + (o < Nc ? o : Nc - 1)];
+      const int o = ll + HL * j;
+      ci[j] = cl[(size_t)sl * Nc + (o < Nc ? o : Nc - 1)];
     }
 #pragma unroll
     for (int j = 0; j < FP; ++j)
     {
-      const int o = lane + 64 * j, oc = o < Nf ? o : Nf - 1;
+      const int o = ll + HL * j, oc = o < Nf ? o : Nf - 1;
       const int a = oc / (ndf * ndf), r = oc - a * ndf * ndf, b = r / ndf, c = r - b * ndf;
-      fi[j] = fl[(size_t)slot * Nf + ftab(ndf, a, b, c)];
+      fi[j] = fl[(size_t)sl * Nf + ftab(ndf, a, b, c)];
     }
   };
-  if (wave < nc)
-    fetch(wave, fcur, ccur);
-  for (int slot = wave; slot < nc; slot += nw)
+  if (wave * CPW < nc)
+    fetch(wave * CPW + half, fcur, ccur);
+  for (int slot0 = wave * CPW; slot0 < nc; slot0 += nw * CPW)
   {
-    if (slot + nw < nc)
-      fetch(slot + nw, fnxt, cnxt);
+    const int slot = slot0 + half;
+    const bool mine = slot < nc;
+    if (slot0 + nw * CPW < nc)
+      fetch(slot + nw * CPW, fnxt, cnxt);
 #pragma unroll
     for (int j = 0; j < FP; ++j)
     {
-      const int o = lane + 64 * j;
+      const int o = ll + HL * j;
       if (o < Nf)
         w[o] = sf[fcur[j]];
     }
     tfence();
-    for (int o = lane; o < n2; o += 64) // (a, b, k): sum over c
+    for (int o = ll; o < n2; o += HL) // (a, b, k): sum over c
     {
       const int ab = o / ndc, k = o - ab * ndc;
       double v = 0.0;
@@ -421,7 +455,7 @@ __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__
       t2[o] = v;
     }
     tfence();
-    for (int o = lane; o < n1; o += 64) // (a, j, k): sum over b
+    for (int o = ll; o < n1; o += HL) // (a, j, k): sum over b
     {
       const int a = o / (ndc * ndc), r = o - a * ndc * ndc, j = r / ndc, k = r - j * ndc;
       double v = 0.0;
@@ -434,7 +468,7 @@ __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__
 #pragma unroll
     for (int jj = 0; jj < CP; ++jj) // (i, j, k): sum over a
     {
-      const int o = lane + 64 * jj;
+      const int o = ll + HL * jj;
       if (o < Nc)
       {
         const int i = o / (ndc * ndc), jk = o - i * ndc * ndc;
@@ -442,7 +476,8 @@ __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__
         #pragma unroll
         for (int a = 0; a < ndf; ++a)
           v += sM[a * ndc + i] * t1[a * ndc * ndc + jk];
-        atomicAdd(&sc[ccur[jj]], v); // in LDS
+        if (mine)
+          atomicAdd(&sc[ccur[jj]], v); // in LDS
       }
     }
     tfence();
@@ -456,12 +491,18 @@ __global__ void restrict_patch_kernel(TransferArgs A, const double* __restrict__
   tbarrier();
   if (atomic_out) // single launch over all patches, coarse zero-filled beforehand
   {
-    for (int i = t; i < Mc; i += blockDim.x)
+    if (t < Mc)
+      atomicAdd(&coarse[cm & PD_MASK], sc[t]);
+    for (int i = t + nthr; i < Mc; i += nthr)
       atomicAdd(&coarse[A.cpdofs[coff + i] & PD_MASK], sc[i]);
   }
   else
-    for (int i = t; i < Mc; i += blockDim.x)
+  {
+    if (t < Mc)
+      coarse[cm & PD_MASK] = sc[t];
+    for (int i = t + nthr; i < Mc; i += nthr)
       coarse[A.cpdofs[coff + i] & PD_MASK] = sc[i];
+  }
 }
 
 // (coarse nd, fine nd) -> kernel instantiation
@@ -843,7 +884,7 @@ extern "C" int pmg_interpolator_create_with_operator(
   }
   // LDS: table + coarse list + fine list + per-wave scratch
   const int ndc = ip->ndc, ndf = ip->ndf;
-  const size_t per_wave = (size_t)ip->Nf + ndf * ndc * ndc + ndf * ndf * ndc;
+  const size_t per_wave = (size_t)transfer_cpw(ndf) * ((size_t)ip->Nf + ndf * ndc * ndc + ndf * ndf * ndc);
   const size_t base = (size_t)ndf * ndc + cmax + v.max_m;
   int waves = 8;
   if (const char* e = std::getenv("PMG_TRANSFER_WAVES")) // tuning: waves per patch (1 .. 16)
