@@ -749,9 +749,9 @@ def main():
     def make_amg(**kw):
         """The coarse solver: on several ranks the replicated hierarchy (global degree-1 matrix on every rank,
         one all-reduce per solve), on one rank the plain one."""
-        if multi:
+        if multi:  # first coarsening per rank, only level 1 gathered: no rank holds the global degree-1 matrix
             return pm.AmgSolver(H.operators[0], global_index=H.levels[0].local_to_global,
-                                n_global=H.part.global_ndofs(orders[0]), **kw)
+                                n_global=H.part.global_ndofs(orders[0]), setup="distributed", **kw)
         return pm.AmgSolver(H.operators[0], **kw)
 
     def _amg_coarse():
@@ -823,7 +823,7 @@ def main():
         t_setup = time.perf_counter()
         if multi:
             amg5 = pm.AmgSolver(H5.operators[0], global_index=H5.levels[0].local_to_global,
-                                n_global=H5.part.global_ndofs(1), cycles=2)
+                                n_global=H5.part.global_ndofs(1), cycles=2, setup="distributed")
         else:
             amg5 = pm.AmgSolver(H5.operators[0], cycles=2)
         torch.cuda.synchronize()

@@ -76,6 +76,7 @@ struct Options : examples::RankOptions
   bool pcg = false, coarse_cg = false, use_amg = false, random_rhs = false, graph = false;
   std::string output;
   pmg_amd::NodeOrder node_order = pmg_amd::NodeOrder::ascending; // of the dofmaps handed to the library
+  bool amg_gather = false; // --amg-setup gathered
 };
 using examples::parse3;
 
@@ -198,9 +199,10 @@ void solve(const Options& o)
   if (o.use_amg)
   {
     auto t0 = std::chrono::steady_clock::now();
-    if (size > 1) // the global degree-1 matrix on every rank: one all-reduce per coarse solve
+    if (size > 1) // first coarsening per rank, level 1 gathered on every rank (--amg-setup gathered: the global
+                  // degree-1 matrix on every rank instead); one all-reduce of a level-1 vector per cycle
       coarse_solver = std::make_shared<CoarseSolverType<T>>(*operators[0], maps[0], V[0]->lv.local_to_global,
-                                                           mesh.global_ndofs(order[0]));
+                                                           mesh.global_ndofs(order[0]), o.amg_gather);
     else
       coarse_solver = std::make_shared<CoarseSolverType<T>>(*operators[0], maps[0]);
     if (o.amg_cycles > 0)
@@ -395,6 +397,13 @@ int main(int argc, char** argv)
       }
       else if (!std::strcmp(argv[i], "--id-file"))
         o.id_file = next();
+      else if (!std::strcmp(argv[i], "--amg-setup"))
+      {
+        const std::string v = next();
+        if (v != "gathered" && v != "distributed")
+          throw std::runtime_error("--amg-setup distributed | gathered");
+        o.amg_gather = v == "gathered";
+      }
       else if (!std::strcmp(argv[i], "--node-order"))
       {
         const std::string v = next();
@@ -415,7 +424,7 @@ int main(int argc, char** argv)
                      "           [--cycles C] [--pcg [--random-rhs]] [--amg | --amg-cycles N | --coarse-cg] [--graph]\n"
                      "           [--ranks px,py,pz [--rank r] [--id-file F]] [--native-comm] [--halo exchange|windows]\n"
                      "           [--comm rccl|windows]\n"
-                     "           [--node-order ascending|basix]\n"
+                     "           [--node-order ascending|basix] [--amg-setup distributed|gathered]\n"
                      "           [--output FILE]\n"
                      "           [--check-partition px,py,pz]\n";
         return !std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h") ? 0 : 2;

@@ -486,6 +486,17 @@ int pmg_multigrid_set_coarse_callback(pmg_multigrid mg, pmg_coarse_solve_fn solv
 int pmg_amg_create(pmg_amg* out, pmg_laplacian op, pmg_stream stream);
 int pmg_amg_create_replicated(pmg_amg* out, pmg_laplacian op, const int64_t* global_index, int64_t n_global,
                               pmg_stream stream);
+/* The same solver set up WITHOUT gathering the global degree-1 matrix (round 4): every rank aggregates its owned
+ * dofs on its own block (ghost couplings lumped), smooths its prolongator rows with that block, obtains the prolongator
+ * rows of its ghost dofs through the layout's own forward scatter (one layer of overlap; any exchange mechanism),
+ * forms its rows of P^T A P, and only level 1 -- about 1/9 of level 0 -- is gathered and coarsened further on every
+ * rank.  The solve is the replicated form's with the distributed fine level (level 0 smoothed on the partitioned
+ * operator, one all-reduce of a level-1 vector per cycle); pmg_amg_set_distributed_fine_level(amg, 0) is refused.
+ * The hierarchy depends on the partition (aggregates do not cross rank boundaries): 12 CG iterations against the
+ * gathered (= single-rank) hierarchy's 9 on eight ranks of 12^3 cells (tests/test_gpu_distributed.py), 40 for the
+ * rank-local block preconditioner of pmg_amg_create.  Collective. */
+int pmg_amg_create_distributed(pmg_amg* out, pmg_laplacian op, const int64_t* global_index, int64_t n_global,
+                               pmg_stream stream);
 int pmg_amg_destroy(pmg_amg amg);
 int pmg_amg_set_smoother_iterations(pmg_amg amg, int k); /* Chebyshev degree per pre/post smooth (2) */
 int pmg_amg_set_cycles(pmg_amg amg, int cycles);

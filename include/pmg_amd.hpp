@@ -806,15 +806,20 @@ public:
   {
     check(pmg_amg_create(&_a, coarse_operator.handle(map), nullptr));
   }
-  /// Several ranks: the global coarse matrix gathered on every rank (`local_to_global` as dolfinx's
-  /// IndexMap gives it: owned dofs, then ghosts), one all-reduce per solve.
+  /// Several ranks (`local_to_global` as dolfinx's IndexMap gives it: owned dofs, then ghosts).  By default the first
+  /// coarsening is done per rank and only level 1 is gathered (pmg_amg_create_distributed: no rank holds the global
+  /// degree-1 matrix); gather_level0 = true gathers the global matrix on every rank instead (the single-rank
+  /// hierarchy on every rank, pmg_amg_create_replicated).  Either way one all-reduce of a level-1 vector per cycle.
   template <typename Operator>
   AmgSolver(Operator& coarse_operator, const std::shared_ptr<const IndexMap>& map,
-            std::span<const std::int64_t> local_to_global, std::int64_t size_global)
+            std::span<const std::int64_t> local_to_global, std::int64_t size_global, bool gather_level0 = false)
   {
     if ((std::int64_t)local_to_global.size() != (std::int64_t)map->size_local() + map->num_ghosts())
       throw std::runtime_error("AmgSolver: local_to_global must cover owned and ghost dofs");
-    check(pmg_amg_create_replicated(&_a, coarse_operator.handle(map), local_to_global.data(), size_global, nullptr));
+    if (gather_level0)
+      check(pmg_amg_create_replicated(&_a, coarse_operator.handle(map), local_to_global.data(), size_global, nullptr));
+    else
+      check(pmg_amg_create_distributed(&_a, coarse_operator.handle(map), local_to_global.data(), size_global, nullptr));
   }
   AmgSolver(const AmgSolver&) = delete;
   AmgSolver& operator=(const AmgSolver&) = delete;

@@ -151,6 +151,7 @@ _SIGS = {
     "pmg_multigrid_set_coarse_amg": (C.c_int, [vp, vp]),
     "pmg_amg_create": (C.c_int, [C.POINTER(vp), vp, vp]),
     "pmg_amg_create_replicated": (C.c_int, [C.POINTER(vp), vp, C.POINTER(C.c_int64), C.c_int64, vp]),
+    "pmg_amg_create_distributed": (C.c_int, [C.POINTER(vp), vp, C.POINTER(C.c_int64), C.c_int64, vp]),
     "pmg_amg_destroy": (C.c_int, [vp]),
     "pmg_amg_set_smoother_iterations": (C.c_int, [vp, C.c_int]),
     "pmg_amg_set_cycles": (C.c_int, [vp, C.c_int]),

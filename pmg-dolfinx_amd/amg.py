@@ -21,7 +21,7 @@ class AmgSolver:
     operator with no host synchronisation (single rank)."""
 
     def __init__(self, op, max_iter: int = 60, rtol: float = 1e-5, cycles: int = 0, smoother_iterations: int = 2,
-                 global_index=None, n_global=None, distributed_fine_level=None):
+                 global_index=None, n_global=None, distributed_fine_level=None, setup="gathered"):
         """``global_index`` (local -> global dof numbers, owned then ghosts) and ``n_global``: the replicated
         form for several ranks -- the hierarchy built on the gathered global matrix on every rank; by default only
         the levels below the first stay replicated in the solve (``distributed_fine_level``, see
@@ -32,8 +32,10 @@ class AmgSolver:
             gi = np.ascontiguousarray(global_index, dtype=np.int64)
             if gi.size != op.layout.total:
                 raise ValueError("global_index must have size_local + num_ghosts entries")
-            call("pmg_amg_create_replicated", C.byref(h), op.handle, gi.ctypes.data_as(C.POINTER(C.c_int64)),
-                 int(n_global), current_stream())
+            # setup = "gathered": the global degree-1 matrix on every rank (pmg_amg_create_replicated);
+            # "distributed": the first coarsening per rank, only level 1 gathered (pmg_amg_create_distributed)
+            call({"gathered": "pmg_amg_create_replicated", "distributed": "pmg_amg_create_distributed"}[setup],
+                 C.byref(h), op.handle, gi.ctypes.data_as(C.POINTER(C.c_int64)), int(n_global), current_stream())
         else:
             call("pmg_amg_create", C.byref(h), op.handle, current_stream())
         self._handle = h

@@ -629,6 +629,7 @@ struct pmg_amg_s
   // only the levels below it are replicated.  A cycle then moves ONE all-reduce of a level-1 vector (1/9 of the
   // level-0 size) instead of a level-0 one, and every rank smooths its own share of level 0 instead of all of it.
   bool dist0 = false;
+  bool distributed_setup = false; // level 0 was never gathered: the fully replicated solve is not available
   DevCsr P0l, R0l; // the level 0 -> 1 transfer restricted to the owned dofs: [size_local x n1], [n1 x size_local]
   double *d0_r = nullptr, *d0_z = nullptr, *d0_q = nullptr, *d0_b = nullptr, *d0_xc = nullptr; // on the layout
   pmg_cg cg0 = nullptr; // Krylov mode on the layout (distributed dot products)
@@ -642,7 +643,11 @@ namespace
 int alloc_d(double** p, size_t n)
 {
   PMG_HIP(hipMalloc(p, sizeof(double) * std::max<size_t>(n, 1)));
+  // hipMemset runs on the NULL stream and returns before it has run; the caller's stream is usually a non-blocking
+  // one (torch's), which the null stream does not order: a kernel issued there right behind this call could be
+  // overtaken by the fill (seen once as a smoother with a zero diagonal).  Set-up code: wait for it.
   PMG_HIP(hipMemset(*p, 0, sizeof(double) * std::max<size_t>(n, 1)));
+  PMG_HIP(hipStreamSynchronize(nullptr));
   return PMG_OK;
 }
 
@@ -892,8 +897,12 @@ int amg_solve(pmg_amg amg, double* x, const double* b, hipStream_t s)
 
 
 // `global_index` == nullptr: the hierarchy of this rank's own block.  Otherwise the replicated form.
+static int amg_create_distributed_tail(pmg_amg amg, HostCsr&& A0, const int64_t* global_index, int64_t n_global,
+                                       const std::vector<int8_t>& bc, hipStream_t s);
+
+// distributed_setup: the first coarsening per rank, only the levels below it gathered (pmg_amg_create_distributed)
 static int amg_create(pmg_amg* out, pmg_laplacian op, const int64_t* global_index, int64_t n_global,
-                      pmg_stream stream)
+                      pmg_stream stream, bool distributed_setup = false)
 {
   PMG_REQUIRE(out && op, "pmg_amg_create: NULL argument");
   const LaplacianInputs in = laplacian_inputs(op);
@@ -1050,6 +1059,14 @@ static int amg_create(pmg_amg* out, pmg_laplacian op, const int64_t* global_inde
   }
 
   tmc.lap("level-0 assembly");
+  if (replicated && distributed_setup)
+  {
+    PMG_TRY(amg_create_distributed_tail(amg, std::move(A0), global_index, n_global, bc, s));
+    tmc.lap("distributed first coarsening + hierarchy below it");
+    PMG_HIP(hipStreamSynchronize(s));
+    *out = guard.release();
+    return PMG_OK;
+  }
   size_t level0_len = (size_t)total;
   if (replicated)
   {
@@ -1261,6 +1278,477 @@ int build_hierarchy(pmg_amg amg, HostCsr&& A0, size_t level0_len)
 }
 } // namespace
 
+// ---- distributed set-up (round 4): the first coarsening per rank ------------------------------------------------
+// pmg_amg_create_replicated gathers the GLOBAL degree-1 matrix on every rank and coarsens it there (2.1 M rows and
+// ~2.5 s per rank at 8 x 64^3).  Here no rank ever holds the global level-0 matrix:
+//   * every rank aggregates its OWNED dofs (aggregates do not cross rank boundaries) and numbers its aggregates
+//     globally by the smallest global dof number among their members (one all-reduce of a marker vector; no rank
+//     numbers needed);
+//   * the tentative prolongator of the ghost dofs (aggregate number, weight) arrives through the layout's own forward
+//     scatter, so the owned rows of P_0 = (I - omega D^-1 A_0) T are smoothed with the FULL rows of A_0 (a first
+//     version smoothed with the rank's own block only: 13 instead of 9 iterations on 8 ranks);
+//   * A_0 P_0 on the owned rows needs the rows of P_0 of the ghost dofs: ONE layer of overlap, moved as padded
+//     (column, value) tables through the same forward scatter -- any exchange mechanism, callbacks included;
+//   * every rank forms its SHARE of A_1 = P_0^T A_0 P_0 (the sum over its owned fine rows) and level 1 -- about 1/9 of
+//     level 0 -- is the sum of the shares, gathered on every rank as (position, value) pairs in per-rank segments of
+//     one all-reduced array; the hierarchy below it is built and solved replicated, exactly as the solve phase has done
+//     since round 3 (level 0 smoothed on the partitioned operator, one all-reduce of a level-1 vector per cycle);
+//   * the smoothing bound of level 0 comes from a power method on the partitioned matrix-free operator.
+namespace
+{
+// max over the ranks of a small non-negative integer (< 4096), from sums: a unary code
+int allreduce_max_small(pmg_layout l, int v, int* out, hipStream_t s)
+{
+  std::vector<double> code(4096, 0.0);
+  PMG_REQUIRE(v >= 0 && v < 4096, "pmg_amg: a row with %d entries", v);
+  code[v] = 1.0;
+  PMG_TRY(host_allreduce_sum(l, code.data(), code.size(), s));
+  int m = 0;
+  for (int w = 0; w < 4096; ++w)
+    if (code[w] > 0.0)
+      m = w;
+  *out = m;
+  return PMG_OK;
+}
+
+// rows given by (global row, global column, value) on their owners -> the global matrix on every rank
+int gather_rows(pmg_layout l, int n_rows_global, const std::vector<int>& my_rows, const HostCsr& mine /* columns global */,
+                HostCsr& out, hipStream_t s)
+{
+  int wloc = 0;
+  for (int i = 0; i < mine.n; ++i)
+    wloc = std::max(wloc, mine.rp[i + 1] - mine.rp[i]);
+  int W = 1;
+  PMG_TRY(allreduce_max_small(l, wloc, &W, s));
+  W = std::max(W, 1);
+  const size_t ng = (size_t)n_rows_global;
+  std::vector<double> gc(ng * W, 0.0), gv(ng * W, 0.0);
+  for (int i = 0; i < mine.n; ++i)
+  {
+    const size_t g = (size_t)my_rows[i];
+    int k = 0;
+    for (int e = mine.rp[i]; e < mine.rp[i + 1]; ++e, ++k)
+    {
+      gc[g * W + k] = (double)(mine.ci[e] + 1); // column + 1: 0 = empty slot
+      gv[g * W + k] = mine.v[e];
+    }
+  }
+  PMG_TRY(host_allreduce_sum(l, gc.data(), gc.size(), s));
+  PMG_TRY(host_allreduce_sum(l, gv.data(), gv.size(), s));
+  out = HostCsr();
+  out.n = out.m = (int)ng;
+  out.rp.assign(ng + 1, 0);
+  const int nbk = ((int)ng + ROW_BLOCK - 1) / ROW_BLOCK;
+  std::vector<std::vector<int>> bci(nbk);
+  std::vector<std::vector<double>> bv(nbk);
+  std::atomic<long long> unowned(-1);
+  for_row_blocks((int)ng, [&](int blk, int r0, int r1, int) {
+    std::vector<std::pair<int, double>> row;
+    for (int g = r0; g < r1; ++g)
+    {
+      row.clear();
+      for (int k = 0; k < W; ++k)
+        if (gc[(size_t)g * W + k] > 0.5)
+          row.emplace_back((int)(gc[(size_t)g * W + k] - 0.5), gv[(size_t)g * W + k]);
+      if (row.empty())
+        unowned.store(g);
+      std::sort(row.begin(), row.end());
+      for (auto& e : row)
+      {
+        bci[blk].push_back(e.first);
+        bv[blk].push_back(e.second);
+      }
+      out.rp[g + 1] = (int)row.size();
+    }
+  });
+  PMG_REQUIRE(unowned.load() < 0, "pmg_amg: coarse row %lld is owned by no rank", unowned.load());
+  assemble_blocks(out, bci, bv);
+  return PMG_OK;
+}
+
+// largest eigenvalue of D^-1 A of the PARTITIONED operator by the power method on the device (the operator's own halo
+// exchange, the layout's reductions); the start vector depends on the global dof number only, so every partition of the
+// same problem iterates on the same vector
+int lambda_max_distributed(pmg_amg amg, const int64_t* global_index, const double* dinv_d, int its, double* lam,
+                           hipStream_t s)
+{
+  pmg_layout l = amg->layout;
+  const int n = l->size_local, total = l->total();
+  std::vector<double> x0(total, 0.0);
+  for (int i = 0; i < n; ++i)
+  {
+    uint64_t h = (uint64_t)global_index[i] * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    x0[i] = 0.5 + 0.5 * (double)(h >> 11) / 9007199254740992.0;
+  }
+  double *x = amg->d0_r, *q = amg->d0_q;
+  PMG_HIP(hipMemcpyAsync(x, x0.data(), sizeof(double) * total, hipMemcpyHostToDevice, s));
+  PMG_HIP(hipStreamSynchronize(s));
+  double value = 1.0;
+  for (int it = 0; it < its; ++it)
+  {
+    PMG_TRY(laplacian_apply(amg->op, x, q, s));
+    launch_pointwise(n, q, q, dinv_d, s);
+    double qq = 0.0, xx = 0.0;
+    PMG_TRY(dot_host(l, q, q, &qq, s));
+    PMG_TRY(dot_host(l, x, x, &xx, s));
+    if (!(qq > 0.0) || !(xx > 0.0))
+      break;
+    value = std::sqrt(qq / xx);
+    PMG_HIP(hipMemcpyAsync(x, q, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    PMG_TRY(pmg_vec_scale(l, x, 1.0 / std::sqrt(qq), (pmg_stream)s));
+  }
+  *lam = value;
+  return PMG_OK;
+}
+} // namespace
+
+// one scalar per local dof moved owner -> ghost through the layout's forward scatter (host arrays of `total` entries)
+static int host_scatter_fwd(pmg_layout layout, std::vector<double>& h, double* dv, hipStream_t s)
+{
+  const int n = layout->size_local, total = layout->total(), ng = total - n;
+  PMG_HIP(hipMemcpyAsync(dv, h.data(), sizeof(double) * total, hipMemcpyHostToDevice, s));
+  PMG_TRY(pmg_scatter_fwd_begin(layout, dv, (pmg_stream)s));
+  PMG_TRY(pmg_scatter_fwd_end(layout, dv, (pmg_stream)s));
+  if (ng > 0)
+    PMG_HIP(hipMemcpyAsync(h.data() + n, dv + n, sizeof(double) * ng, hipMemcpyDeviceToHost, s));
+  PMG_HIP(hipStreamSynchronize(s));
+  return PMG_OK;
+}
+
+static int amg_create_distributed_tail(pmg_amg amg, HostCsr&& A0, const int64_t* global_index, int64_t n_global,
+                                       const std::vector<int8_t>& bc, hipStream_t s)
+{
+  pmg_layout layout = amg->layout;
+  const int n = layout->size_local, total = layout->total(), ng = total - n;
+  amg->distributed_setup = true;
+  (void)bc;
+  StageTimer tm;
+  const std::vector<double> d = diagonal(A0); // the diagonal of the owned rows: the smoother's D
+  for (int i = 0; i < n; ++i)
+    PMG_REQUIRE(d[i] > 0.0, "pmg_amg_create_distributed: row %d has no positive diagonal", i);
+  // what the solve needs on the layout, and the smoothing bound of level 0 first (the prolongator uses it)
+  PMG_TRY(alloc_d(&amg->d0_r, total));
+  PMG_TRY(alloc_d(&amg->d0_z, total));
+  PMG_TRY(alloc_d(&amg->d0_q, total));
+  PMG_TRY(alloc_d(&amg->d0_b, total));
+  PMG_TRY(alloc_d(&amg->d0_xc, total));
+  {
+    std::vector<double> dinv(total, 1.0);
+    for (int i = 0; i < n; ++i)
+      dinv[i] = 1.0 / d[i];
+    PMG_TRY(to_device(&amg->d0_dinv, dinv));
+  }
+  double lam0 = 1.0;
+  PMG_TRY(lambda_max_distributed(amg, global_index, amg->d0_dinv, 20, &lam0, s));
+  const double rho0 = 1.05 * lam0;
+  tm.lap("level-0 bound (power method on the partitioned operator)");
+
+  // (A) aggregation of the OWNED dofs on the rank's own block (aggregates do not cross rank boundaries)
+  HostCsr Aown;
+  Aown.n = Aown.m = n;
+  Aown.rp.assign(n + 1, 0);
+  for (int i = 0; i < n; ++i)
+  {
+    for (int e = A0.rp[i]; e < A0.rp[i + 1]; ++e)
+      if (A0.ci[e] < n)
+      {
+        Aown.ci.push_back(A0.ci[e]);
+        Aown.v.push_back(A0.v[e]);
+      }
+    Aown.rp[i + 1] = (int)Aown.ci.size();
+  }
+  std::vector<int> agg;
+  const int na = aggregate(Aown, d, 0.08, agg);
+  Aown = HostCsr();
+  std::vector<int> size(std::max(na, 1), 0);
+  for (int i = 0; i < n; ++i)
+    if (agg[i] >= 0)
+      size[agg[i]]++;
+  tm.lap("aggregation of the owned dofs");
+
+  // (B) global numbers of the aggregates: rank among all aggregates' smallest global member
+  std::vector<int64_t> root(na, INT64_MAX);
+  for (int i = 0; i < n; ++i)
+    if (agg[i] >= 0)
+      root[agg[i]] = std::min(root[agg[i]], global_index[i]);
+  std::vector<double> marker((size_t)n_global, 0.0);
+  for (int a = 0; a < na; ++a)
+  {
+    PMG_REQUIRE(root[a] != INT64_MAX, "pmg_amg_create_distributed: empty aggregate");
+    marker[(size_t)root[a]] = 1.0;
+  }
+  PMG_TRY(host_allreduce_sum(layout, marker.data(), marker.size(), s));
+  int n1 = 0;
+  {
+    std::vector<int32_t> cid((size_t)n_global, -1);
+    for (int64_t g = 0; g < n_global; ++g)
+      if (marker[(size_t)g] > 0.5)
+      {
+        PMG_REQUIRE(marker[(size_t)g] < 1.5, "pmg_amg_create_distributed: dof %lld is owned by two ranks", (long long)g);
+        cid[(size_t)g] = n1++;
+      }
+    for (int a = 0; a < na; ++a)
+      root[a] = cid[(size_t)root[a]]; // from here on: the aggregate's global number
+  }
+  PMG_REQUIRE(n1 > 0, "pmg_amg_create_distributed: nothing to coarsen");
+  tm.lap("global aggregate numbers");
+
+  // (C) the tentative prolongator on owned AND ghost dofs (aggregate number + 1 and weight 1 / sqrt(size): one scalar
+  // exchange each), then the owned rows of P_0 = (I - 4 / (3 rho) D^-1 A_0) T with the FULL rows of A_0 -- ghost
+  // couplings included, so the columns of a rank's rows may be neighbours' aggregates
+  double* dv = nullptr;
+  PMG_HIP(hipMalloc(&dv, sizeof(double) * std::max(total, 1)));
+  std::vector<double> tcol(total, 0.0), tval(total, 0.0);
+  for (int i = 0; i < n; ++i)
+    if (agg[i] >= 0)
+    {
+      tcol[i] = (double)(root[agg[i]] + 1);
+      tval[i] = 1.0 / std::sqrt((double)size[agg[i]]);
+    }
+  int rc = host_scatter_fwd(layout, tcol, dv, s);
+  if (rc == PMG_OK)
+    rc = host_scatter_fwd(layout, tval, dv, s);
+  if (rc != PMG_OK)
+  {
+    (void)hipFree(dv);
+    return rc;
+  }
+  const double omega = 4.0 / (3.0 * rho0);
+  HostCsr Pl; // [n x n1], global coarse columns
+  Pl.n = n;
+  Pl.m = n1;
+  Pl.rp.assign(n + 1, 0);
+  {
+    const int nb = (n + ROW_BLOCK - 1) / ROW_BLOCK, T = host_threads();
+    std::vector<std::vector<int>> bci(nb), markers(T);
+    std::vector<std::vector<double>> bv(nb), accs(T);
+    for_row_blocks(n, [&](int blk, int r0, int r1, int th) {
+      if (markers[th].empty())
+      {
+        markers[th].assign(n1, -1);
+        accs[th].assign(n1, 0.0);
+      }
+      std::vector<int>& mk = markers[th];
+      std::vector<double>& ac = accs[th];
+      std::vector<int> cols;
+      for (int i = r0; i < r1; ++i)
+      {
+        cols.clear();
+        auto add = [&](int c, double val) {
+          if (mk[c] != i)
+          {
+            mk[c] = i;
+            ac[c] = 0.0;
+            cols.push_back(c);
+          }
+          ac[c] += val;
+        };
+        if (tcol[i] > 0.5)
+        {
+          add((int)(tcol[i] - 0.5), tval[i]);
+          for (int e = A0.rp[i]; e < A0.rp[i + 1]; ++e)
+          {
+            const int j = A0.ci[e];
+            if (tcol[j] > 0.5)
+              add((int)(tcol[j] - 0.5), -omega * A0.v[e] / d[i] * tval[j]);
+          }
+        }
+        std::sort(cols.begin(), cols.end());
+        int len = 0;
+        for (int c : cols)
+          if (ac[c] != 0.0)
+          {
+            bci[blk].push_back(c);
+            bv[blk].push_back(ac[c]);
+            ++len;
+          }
+        Pl.rp[i + 1] = len;
+      }
+    });
+    assemble_blocks(Pl, bci, bv);
+  }
+  tm.lap("smoothed prolongator (owned rows)");
+
+  // (D) rows of P_0 of the ghost dofs: padded (column + 1, value) tables through the layout's forward scatter
+  int wloc = 0, Wp = 0;
+  for (int i = 0; i < n; ++i)
+    wloc = std::max(wloc, Pl.rp[i + 1] - Pl.rp[i]);
+  rc = allreduce_max_small(layout, wloc, &Wp, s);
+  HostCsr Pext; // [total x n1]: owned rows, then the ghosts' rows
+  Pext.n = total;
+  Pext.m = n1;
+  Pext.rp.assign(total + 1, 0);
+  {
+    std::vector<double> gcols((size_t)ng * std::max(Wp, 1), 0.0), gvals((size_t)ng * std::max(Wp, 1), 0.0);
+    std::vector<double> h(total, 0.0);
+    for (int k = 0; k < Wp && rc == PMG_OK; ++k)
+      for (int what = 0; what < 2 && rc == PMG_OK; ++what)
+      {
+        for (int i = 0; i < n; ++i)
+        {
+          const int e = Pl.rp[i] + k;
+          h[i] = e < Pl.rp[i + 1] ? (what == 0 ? (double)(Pl.ci[e] + 1) : Pl.v[e]) : 0.0;
+        }
+        rc = host_scatter_fwd(layout, h, dv, s);
+        for (int g = 0; g < ng && rc == PMG_OK; ++g)
+          (what == 0 ? gcols : gvals)[(size_t)g * Wp + k] = h[n + g];
+      }
+    (void)hipFree(dv);
+    PMG_TRY(rc);
+    Pext.ci = Pl.ci;
+    Pext.v = Pl.v;
+    for (int i = 0; i < n; ++i)
+      Pext.rp[i + 1] = Pl.rp[i + 1];
+    for (int g = 0; g < ng; ++g)
+    {
+      for (int k = 0; k < Wp; ++k)
+        if (gcols[(size_t)g * Wp + k] > 0.5)
+        {
+          const int c = (int)(gcols[(size_t)g * Wp + k] - 0.5);
+          PMG_REQUIRE(c >= 0 && c < n1, "pmg_amg_create_distributed: a ghost's prolongator row names aggregate %d", c);
+          Pext.ci.push_back(c);
+          Pext.v.push_back(gvals[(size_t)g * Wp + k]);
+        }
+      Pext.rp[n + g + 1] = (int)Pext.ci.size();
+    }
+  }
+  tm.lap("prolongator rows of the ghosts (one layer of overlap)");
+
+  // (E) this rank's SHARE of A_1 = P_0^T A_0 P_0: sum over its owned fine rows i of P_i^T (A_0 P_0)_i -- entries in the
+  // rows of its own aggregates and, along the interfaces, of its neighbours'
+  HostCsr A1part = spgemm(transpose(Pl), spgemm(A0, Pext)); // [n1 x n1], non-empty only in the rows this rank touches
+  tm.lap("Galerkin product of the owned rows");
+
+  // (F) level 1 on every rank = the sum of the shares: (row * n1 + column, value) pairs in the rank's own segment of one
+  // long array (segments ordered by the rank's smallest owned global dof number: no rank numbers needed), summed over
+  // the ranks, then assembled row by row
+  HostCsr A1;
+  {
+    const long long cnt = A1part.nnz();
+    int64_t mykey = INT64_MAX;
+    for (int i = 0; i < n; ++i)
+      mykey = std::min(mykey, global_index[i]);
+    std::fill(marker.begin(), marker.end(), 0.0);
+    PMG_REQUIRE(n == 0 || mykey != INT64_MAX, "pmg_amg_create_distributed: no owned dof");
+    if (n > 0)
+      marker[(size_t)mykey] = (double)cnt + 0.25; // + 0.25: a rank with an empty share still marks its key
+    PMG_TRY(host_allreduce_sum(layout, marker.data(), marker.size(), s));
+    long long offset = 0, totalcnt = 0;
+    for (int64_t g = 0; g < n_global; ++g)
+      if (marker[(size_t)g] > 0.0)
+      {
+        const long long c = (long long)marker[(size_t)g];
+        if (g < mykey)
+          offset += c;
+        totalcnt += c;
+      }
+    std::vector<double>().swap(marker);
+    std::vector<double> keys((size_t)totalcnt, 0.0), vals((size_t)totalcnt, 0.0);
+    {
+      long long o = offset;
+      for (int I = 0; I < n1; ++I)
+        for (int e = A1part.rp[I]; e < A1part.rp[I + 1]; ++e, ++o)
+        {
+          keys[(size_t)o] = (double)((long long)I * n1 + A1part.ci[e]) + 1.0; // + 1: 0 = empty
+          vals[(size_t)o] = A1part.v[e];
+        }
+    }
+    A1part = HostCsr();
+    PMG_TRY(host_allreduce_sum(layout, keys.data(), keys.size(), s));
+    PMG_TRY(host_allreduce_sum(layout, vals.data(), vals.size(), s));
+    // bucket by row, then sort each row by column and add duplicates
+    std::vector<int> rstart(n1 + 1, 0);
+    for (long long o = 0; o < totalcnt; ++o)
+    {
+      PMG_REQUIRE(keys[(size_t)o] > 0.5, "pmg_amg_create_distributed: two ranks share a segment of the gather");
+      rstart[(int)(((long long)(keys[(size_t)o] - 0.5)) / n1) + 1]++;
+    }
+    for (int I = 0; I < n1; ++I)
+      rstart[I + 1] += rstart[I];
+    std::vector<int> ecol((size_t)totalcnt);
+    std::vector<double> eval((size_t)totalcnt);
+    {
+      std::vector<int> pos(rstart.begin(), rstart.end() - 1);
+      for (long long o = 0; o < totalcnt; ++o)
+      {
+        const long long k = (long long)(keys[(size_t)o] - 0.5);
+        const int I = (int)(k / n1), J = (int)(k - (long long)I * n1);
+        const int p = pos[I]++;
+        ecol[(size_t)p] = J;
+        eval[(size_t)p] = vals[(size_t)o];
+      }
+    }
+    std::vector<double>().swap(keys);
+    std::vector<double>().swap(vals);
+    A1.n = A1.m = n1;
+    A1.rp.assign(n1 + 1, 0);
+    const int nbk = (n1 + ROW_BLOCK - 1) / ROW_BLOCK;
+    std::vector<std::vector<int>> bci(nbk);
+    std::vector<std::vector<double>> bv(nbk);
+    for_row_blocks(n1, [&](int blk, int r0, int r1, int) {
+      std::vector<std::pair<int, double>> row;
+      for (int I = r0; I < r1; ++I)
+      {
+        row.clear();
+        for (int p = rstart[I]; p < rstart[I + 1]; ++p)
+          row.emplace_back(ecol[(size_t)p], eval[(size_t)p]);
+        // (stable order of equal columns = order of the ranks' segments: the same sums on every rank)
+        std::stable_sort(row.begin(), row.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+        int len = 0;
+        for (size_t q = 0; q < row.size();)
+        {
+          double v = 0.0;
+          size_t r = q;
+          for (; r < row.size() && row[r].first == row[q].first; ++r)
+            v += row[r].second;
+          bci[blk].push_back(row[q].first);
+          bv[blk].push_back(v);
+          ++len;
+          q = r;
+        }
+        A1.rp[I + 1] = len;
+      }
+    });
+    assemble_blocks(A1, bci, bv);
+  }
+  tm.lap("gather of level 1 (sum of the ranks' shares)");
+  PMG_TRY(build_hierarchy(amg, std::move(A1), (size_t)n1));
+  // (build_hierarchy leaves the solution vector of ITS first level to the caller; here that level is level 1 of the
+  // solve and needs one of its own)
+  PMG_TRY(alloc_d(&amg->levels[0].x, (size_t)n1));
+  // level 0 in front of it: lives on the layout, has no assembled matrix on the device
+  AmgLevel l0;
+  l0.n = n;
+  l0.nnz = A0.nnz();
+  l0.lmax = rho0;
+  amg->levels.insert(amg->levels.begin(), l0);
+  amg->hA.insert(amg->hA.begin(), HostCsr());
+  amg->hP.insert(amg->hP.begin(), Pl);
+  amg->hlmax.insert(amg->hlmax.begin(), rho0);
+
+  PMG_TRY(upload_csr(amg->P0l, Pl));
+  PMG_TRY(upload_csr(amg->R0l, transpose(Pl)));
+  PMG_HIP(hipHostMalloc(&amg->h_stage, sizeof(double) * std::max<size_t>((size_t)std::max(n1, 1), 1), hipHostMallocDefault));
+  PMG_TRY(pmg_layout_create(&amg->glayout, (int32_t)n1, 0, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                            nullptr));
+  PMG_TRY(pmg_cg_create(&amg->cg, amg->glayout));
+  PMG_TRY(pmg_cg_create(&amg->cg0, layout));
+  amg->hA[0] = std::move(A0);
+  amg->dist0 = true;
+  tm.lap("hierarchy below level 1 + uploads");
+  return PMG_OK;
+}
+
+extern "C" int pmg_amg_create_distributed(pmg_amg* out, pmg_laplacian op, const int64_t* global_index,
+                                          int64_t n_global, pmg_stream stream)
+{
+  PMG_REQUIRE(global_index, "pmg_amg_create_distributed: NULL global index");
+  return amg_create(out, op, global_index, n_global, stream, true);
+}
+
 extern "C" int pmg_amg_destroy(pmg_amg amg)
 {
   if (!amg)
@@ -1320,6 +1808,9 @@ extern "C" int pmg_amg_set_distributed_fine_level(pmg_amg amg, int enable)
   PMG_REQUIRE(amg, "pmg_amg_set_distributed_fine_level: NULL argument");
   PMG_REQUIRE(amg->replicated, "pmg_amg_set_distributed_fine_level: not a replicated hierarchy");
   PMG_REQUIRE(!enable || amg->cg0, "pmg_amg_set_distributed_fine_level: the hierarchy has one level only");
+  PMG_REQUIRE(enable || !amg->distributed_setup,
+              "pmg_amg_set_distributed_fine_level: this hierarchy was set up without gathering its level 0 "
+              "(pmg_amg_create_distributed): it cannot be replicated in the solve");
   amg->dist0 = enable != 0;
   return PMG_OK;
 }

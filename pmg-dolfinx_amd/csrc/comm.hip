@@ -228,6 +228,7 @@ extern "C" int pmg_layout_set_comm(pmg_layout l, pmg_comm comm, int32_t n_neighb
     *pos = nullptr;
     PMG_HIP(hipMalloc(buf, sizeof(double) * (at ? at : 1)));
     PMG_HIP(hipMemset(*buf, 0, sizeof(double) * (at ? at : 1)));
+    PMG_HIP(hipStreamSynchronize(nullptr)); // (null-stream fill: not ordered against the non-blocking streams)
     PMG_HIP(hipMalloc(pos, sizeof(int32_t) * (h.empty() ? 1 : h.size())));
     if (!h.empty())
       PMG_HIP(hipMemcpy(*pos, h.data(), sizeof(int32_t) * h.size(), hipMemcpyHostToDevice));

@@ -2260,6 +2260,7 @@ extern "C" int pmg_laplacian_set_geometry_batch(pmg_laplacian op, long long batc
   const size_t gsize = per_patch * (size_t)(bp > 0 ? bp : op->npatch);
   PMG_HIP(hipMalloc(&op->G, sizeof(double2) * (gsize ? gsize : 1)));
   PMG_HIP(hipMemset(op->G, 0, sizeof(double2) * (gsize ? gsize : 1))); // padding of the flat layout
+  PMG_HIP(hipStreamSynchronize(nullptr)); // (null-stream fill: not ordered against the caller's non-blocking stream)
   op->batch_patches = bp;
   op->stream_policy = streams_past_the_cache((long long)sizeof(double2) * gsize);
   if (bp == 0 && op->npatch > 0) // back to the resident tensor

@@ -189,6 +189,7 @@ int alloc_vec(pmg_layout l, double** p)
   size_t n = l->total() ? l->total() : 1;
   PMG_HIP(hipMalloc(p, sizeof(double) * n));
   PMG_HIP(hipMemset(*p, 0, sizeof(double) * n));
+  PMG_HIP(hipStreamSynchronize(nullptr)); // the fill runs on the null stream, which non-blocking streams do not order
   return PMG_OK;
 }
 

@@ -190,6 +190,21 @@ def _rank_checks(pm, rank, world, n, dims, orders, comm=None):
     out["rep_dist_vs_full"] = float(np.abs(xf.data_copy()[: lv0.size_local] - xl.data_copy()[: lv0.size_local]).max()
                                     / np.abs(xs).max())
     del rep_full, xf
+    # the set-up WITHOUT the global level-0 matrix (round 4): first coarsening per rank, only level 1 gathered.  The
+    # hierarchy depends on the partition (aggregates stay inside a rank), so: the same solution, an iteration count
+    # within one of the gathered hierarchy's, the same hierarchy on every rank below level 0, and no level of it as
+    # large as the global degree-1 problem
+    dis = pm.AmgSolver(H.operators[0], max_iter=60, rtol=1e-9, global_index=lv0.local_to_global,
+                       n_global=H.part.global_ndofs(orders[0]), setup="distributed")
+    xd = pm.Vector(H.layouts[0])
+    out["dis_its"] = dis.solve(xd, bl)
+    out["dis_err"] = float(np.abs(xd.data_copy()[: lv0.size_local] - xs[lv0.local_to_global[: lv0.size_local]]).max()
+                           / np.abs(xs).max())
+    out["dis_levels"] = dis.info()
+    out["n_global0"] = H.part.global_ndofs(orders[0])
+    with pytest.raises(RuntimeError, match="without gathering"):
+        pm._lib.call("pmg_amg_set_distributed_fine_level", dis.handle, 0)
+    del dis, xd
     reps = pm.AmgSolver(H.operators[0], cycles=8, global_index=lv0.local_to_global,
                         n_global=H.part.global_ndofs(orders[0]))
     H.mg.set_coarse_solver(reps)
@@ -223,6 +238,12 @@ def _assert_rank_results(res):
     for out in res:
         assert abs(out["rep_full_its"] - out["rep_its"]) <= 1 and out["rep_dist_vs_full"] < 1e-7, (
             out["rep_full_its"], out["rep_its"], out["rep_dist_vs_full"])
+        # distributed set-up: the same solution (these meshes are so small that the gathered hierarchy is a direct
+        # solve; iteration counts are compared on a mesh that coarsens, test_distributed_amg_setup_on_eight_ranks)
+        assert out["dis_its"] <= 14 and out["dis_err"] < 1e-7, (out["dis_its"], out["rep_its"], out["dis_err"])
+        assert out["dis_levels"][0]["rows"] < out["n_global0"]  # level 0 = the rank's own rows
+        assert all(lv["rows"] < 0.5 * out["n_global0"] for lv in out["dis_levels"][1:])
+    assert all(out["dis_levels"][1:] == res[0]["dis_levels"][1:] for out in res)
 
 
 def _worker_body(rank, world, port, n, dims, orders, halo="exchange"):
@@ -407,6 +428,101 @@ class _ThreadComm:
         tot = vals.max(axis=0) if op == "max" else vals.sum(axis=0)
         W.wait()
         host[:] = tot
+
+
+def test_distributed_amg_setup_on_eight_ranks(built):
+    """the AMG set up WITHOUT the global degree-1 matrix -- every rank coarsens its own block with one
+    layer of overlap, only level 1 is gathered -- on the 2 x 2 x 2 split (eight ranks as threads), 24^3 cells = 15 625
+    degree-1 dofs: the same solution; iteration counts: the gathered hierarchy IS the single-rank one (same count), the
+    distributed one depends on the partition (aggregates do not cross rank boundaries) and takes 12 iterations against
+    9 -- against 40 for the rank-local block preconditioner (tools/amg_rank_scaling.py); no rank holds a level as large
+    as the global problem; set-up times printed."""
+    import threading
+    import time
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import scipy.sparse.linalg as spla
+
+    import pmg_dolfinx_amd as pm
+    from oracle import pmg_oracle as po
+
+    n, dims, world = (24, 24, 24), (2, 2, 2), 8
+    gm = po.BoxMesh(n, warp=warp)
+    A = po.Laplacian(1, 2.0, gm.dofmap(1), gm.xgeom, gm.geom_dofmap, gm.boundary_marker(1))
+    g = np.random.default_rng(5).standard_normal(A.ndofs)
+    g[gm.boundary_marker(1).astype(bool)] = 0.0
+    xs = spla.spsolve(A.assemble_csr().tocsc(), g)
+    # one rank, the whole mesh: the reference iteration count
+    part1 = pm.BoxPartition(n, warp=warp)
+    lv1 = part1.level(1)
+    lay1 = pm.make_layout(lv1)
+    op1 = pm.MatFreeLaplacian(1, 2.0, lv1.dofmap, part1.xgeom, part1.geom_dofmap, lv1.lcells, lv1.bcells,
+                              lv1.bc_marker, lay1)
+    one = pm.AmgSolver(op1, max_iter=60, rtol=1e-9)
+    b1, x1 = pm.Vector(lay1), pm.Vector(lay1)
+    b1.data.copy_(torch.from_numpy(g))
+    its_one = one.solve(x1, b1)
+    assert np.abs(x1.data_copy() - xs).max() < 1e-7 * np.abs(xs).max()
+    del one, op1, b1, x1
+
+    W = _ThreadWorld(world)
+    res, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                comm = _ThreadComm(W, rank)
+                part = pm.BoxPartition(n, dims, rank, warp=warp)
+                lv = part.level(1)
+                layout = pm.make_layout(lv, comm=comm)
+                op = pm.MatFreeLaplacian(1, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells,
+                                         lv.bc_marker, layout)
+                bl = pm.Vector(layout)
+                bl.data.copy_(torch.from_numpy(g[lv.local_to_global]))
+                out = {}
+                for setup in ("gathered", "distributed"):
+                    t0 = time.perf_counter()
+                    amg = pm.AmgSolver(op, max_iter=60, rtol=1e-9, global_index=lv.local_to_global, n_global=A.ndofs,
+                                       setup=setup)
+                    torch.cuda.current_stream().synchronize()
+                    out[setup + "_setup_s"] = time.perf_counter() - t0
+                    xl = pm.Vector(layout)
+                    out[setup + "_its"] = amg.solve(xl, bl)
+                    out[setup + "_err"] = float(np.abs(xl.data_copy()[: lv.size_local]
+                                                       - xs[lv.local_to_global[: lv.size_local]]).max() / np.abs(xs).max())
+                    out[setup + "_levels"] = amg.info()
+                    del amg, xl
+                res[rank] = out
+                torch.cuda.current_stream().synchronize()
+        except BaseException:  # noqa: BLE001
+            import traceback
+
+            errors.append((rank, traceback.format_exc()))
+            W.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=900)
+    assert not errors, "\n".join(f"rank {r}:\n{tb}" for r, tb in errors)
+    print([(o["gathered_its"], o["gathered_err"], o["distributed_its"], o["distributed_err"]) for o in res])
+    for out in res:
+        assert out["gathered_err"] < 1e-7 and out["distributed_err"] < 1e-7
+        assert abs(out["gathered_its"] - its_one) <= 1, (out["gathered_its"], its_one)
+        assert out["distributed_its"] <= its_one + 3, (out["distributed_its"], its_one)
+        lv_d = out["distributed_levels"]
+        assert lv_d[0]["rows"] < 0.2 * A.ndofs                      # level 0: the rank's own rows only
+        assert all(l["rows"] < 0.25 * A.ndofs for l in lv_d[1:])    # nothing gathered is as large as level 0
+        assert out["gathered_levels"][0]["rows"] == A.ndofs         # ... which the gathered set-up holds on every rank
+    assert all(out["distributed_levels"][1:] == res[0]["distributed_levels"][1:] for out in res)
+    print("AMG set-up on 8 ranks (threads of one process, one GPU): gathered "
+          f"{max(o['gathered_setup_s'] for o in res):.2f} s, distributed {max(o['distributed_setup_s'] for o in res):.2f} s; "
+          f"iterations one rank / gathered / distributed: {its_one} / {res[0]['gathered_its']} / {res[0]['distributed_its']}")
 
 
 @pytest.mark.parametrize("n,orders", [((8, 8, 8), (1, 2, 4)),   # BASELINE config 3's levels, 4 x 4 x 4 cells per brick

@@ -258,11 +258,13 @@ def test_pmg_driver_ranks_share_the_gpu_through_the_window_communicator(built, d
         assert r.returncode == 0, r.stdout + r.stderr
         return r.stdout
 
-    for extra in ([], ["--amg-cycles", "2"]):
+    for extra in ([], ["--amg-cycles", "2", "--amg-setup", "gathered"], ["--amg-cycles", "2"]):
         one = grab(r"Cycle \d+: residual norm = (\S+)", run("pmg_main", *args, *extra))
         many = grab(r"Cycle \d+: residual norm = (\S+)", ranks(*extra))
         assert len(one) == len(many) == 4
-        tol = 1e-9 if not extra else 1e-5  # the AMG hierarchy of the replicated solve orders its sums differently
+        # no AMG: the same arithmetic; gathered set-up: the same hierarchy, sums ordered differently; distributed set-up
+        # (the default on several ranks): another hierarchy -- aggregates stay inside a rank -- with the same contraction
+        tol = 1e-9 if not extra else 1e-5 if "gathered" in extra else 1e-3
         assert all(abs(a - b) < tol * one[0] for a, b in zip(one, many)), (one, many)
     out = ranks("--graph", "--pcg")
     assert "(hipGraph replays)" in out
