@@ -492,9 +492,9 @@ int pmg_amg_create_replicated(pmg_amg* out, pmg_laplacian op, const int64_t* glo
  * forms its rows of P^T A P, and only level 1 -- about 1/9 of level 0 -- is gathered and coarsened further on every
  * rank.  The solve is the replicated form's with the distributed fine level (level 0 smoothed on the partitioned
  * operator, one all-reduce of a level-1 vector per cycle); pmg_amg_set_distributed_fine_level(amg, 0) is refused.
- * The hierarchy depends on the partition (aggregates do not cross rank boundaries): 12 CG iterations against the
- * gathered (= single-rank) hierarchy's 9 on eight ranks of 12^3 cells (tests/test_gpu_distributed.py), 40 for the
- * rank-local block preconditioner of pmg_amg_create.  Collective. */
+ * The hierarchy depends on the partition (aggregates do not cross rank boundaries); iteration counts stay within one
+ * of the gathered (= single-rank) hierarchy's: 10 against 10 on eight ranks of 64^3 cells
+ * (tools/amg_setup_scaling.py), where the rank-local block preconditioner of pmg_amg_create takes 40.  Collective. */
 int pmg_amg_create_distributed(pmg_amg* out, pmg_laplacian op, const int64_t* global_index, int64_t n_global,
                                pmg_stream stream);
 int pmg_amg_destroy(pmg_amg amg);

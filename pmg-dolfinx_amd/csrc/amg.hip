@@ -733,7 +733,7 @@ int host_allreduce_sum(pmg_layout l, double* v, size_t n, hipStream_t s)
   return PMG_OK;
 }
 
-int build_hierarchy(pmg_amg amg, HostCsr&& A0, size_t level0_len);
+int build_hierarchy(pmg_amg amg, HostCsr&& A0, size_t level0_len, double theta0 = 0.08);
 } // namespace
 
 namespace pmg
@@ -1194,7 +1194,8 @@ extern "C" int pmg_amg_create_replicated(pmg_amg* out, pmg_laplacian op, const i
 
 namespace
 {
-int build_hierarchy(pmg_amg amg, HostCsr&& A0, size_t level0_len)
+// theta0: strength threshold of the first coarsening done here (halved from level to level)
+int build_hierarchy(pmg_amg amg, HostCsr&& A0, size_t level0_len, double theta0)
 {
   StageTimer tm;
   // ---- the hierarchy ----
@@ -1202,7 +1203,7 @@ int build_hierarchy(pmg_amg amg, HostCsr&& A0, size_t level0_len)
   std::vector<HostCsr> As, Ps;
   As.push_back(std::move(A0));
   std::vector<double> lmaxs;
-  double theta = 0.08;
+  double theta = theta0;
   while (true)
   {
     const HostCsr& A = As.back();
@@ -1715,7 +1716,7 @@ static int amg_create_distributed_tail(pmg_amg amg, HostCsr&& A0, const int64_t*
     assemble_blocks(A1, bci, bv);
   }
   tm.lap("gather of level 1 (sum of the ranks' shares)");
-  PMG_TRY(build_hierarchy(amg, std::move(A1), (size_t)n1));
+  PMG_TRY(build_hierarchy(amg, std::move(A1), (size_t)n1, 0.04)); // level 1's threshold: half of level 0's 0.08
   // (build_hierarchy leaves the solution vector of ITS first level to the caller; here that level is level 1 of the
   // solve and needs one of its own)
   PMG_TRY(alloc_d(&amg->levels[0].x, (size_t)n1));

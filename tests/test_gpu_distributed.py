@@ -433,10 +433,10 @@ class _ThreadComm:
 def test_distributed_amg_setup_on_eight_ranks(built):
     """the AMG set up WITHOUT the global degree-1 matrix -- every rank coarsens its own block with one
     layer of overlap, only level 1 is gathered -- on the 2 x 2 x 2 split (eight ranks as threads), 24^3 cells = 15 625
-    degree-1 dofs: the same solution; iteration counts: the gathered hierarchy IS the single-rank one (same count), the
-    distributed one depends on the partition (aggregates do not cross rank boundaries) and takes 12 iterations against
-    9 -- against 40 for the rank-local block preconditioner (tools/amg_rank_scaling.py); no rank holds a level as large
-    as the global problem; set-up times printed."""
+    degree-1 dofs: the same solution; iteration counts within one of the single-rank hierarchy's (the gathered hierarchy
+    IS that hierarchy; the distributed one depends on the partition -- aggregates do not cross rank boundaries; the
+    rank-local block preconditioner of pmg_amg_create takes 40, tools/amg_rank_scaling.py); no rank holds a level as
+    large as the global problem; set-up times printed."""
     import threading
     import time
 
@@ -514,7 +514,7 @@ def test_distributed_amg_setup_on_eight_ranks(built):
     for out in res:
         assert out["gathered_err"] < 1e-7 and out["distributed_err"] < 1e-7
         assert abs(out["gathered_its"] - its_one) <= 1, (out["gathered_its"], its_one)
-        assert out["distributed_its"] <= its_one + 3, (out["distributed_its"], its_one)
+        assert abs(out["distributed_its"] - its_one) <= 1, (out["distributed_its"], its_one)
         lv_d = out["distributed_levels"]
         assert lv_d[0]["rows"] < 0.2 * A.ndofs                      # level 0: the rank's own rows only
         assert all(l["rows"] < 0.25 * A.ndofs for l in lv_d[1:])    # nothing gathered is as large as level 0
