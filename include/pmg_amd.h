@@ -350,8 +350,17 @@ long long pmg_laplacian_geometry_bytes(pmg_laplacian op);
  * the colours are merged into one launch that accumulates with atomics.
  * pmg_set_merge_threshold overrides that limit for operators created afterwards (0: always
  * coloured launches, a huge value: always merged, negative: the defaults above); process-wide,
- * for tests and tuning. */
+ * for tests and tuning.
+ *
+ * Opt-in (PMG_APPLY_STREAMS=1 in the environment when the operator is created; =2 also on small levels, for tests):
+ * the interior of a large level (>= 2048 patches, colours launched one by one) is cut in two halves whose colour
+ * sequences run on two streams -- the caller's and one the operator owns, forked and joined with events; inside a stream
+ * capture they become two branches of the graph -- so that each half fills the other's launch tails.  The halves share
+ * dofs only across the cut; one event between the sequences orders those (patches.hip).  Off by default: the three
+ * events per application cost more than the tails they hide (profiles/kernel_tuning_r04.md).
+ * pmg_laplacian_apply_streams returns 1 or 2. */
 int pmg_laplacian_launches_per_apply(pmg_laplacian op);
+int pmg_laplacian_apply_streams(pmg_laplacian op);
 int pmg_set_merge_threshold(long long patch_dofs);
 /* Dominant-kernel timing hook for bench.py: enqueue `reps` times every
  * stiffness-kernel launch of one operator application (no halo, no zero-fill)

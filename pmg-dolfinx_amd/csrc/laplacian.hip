@@ -78,6 +78,12 @@ struct pmg_laplacian_s
   uint16_t* lmaps = nullptr;   // [nuniq][K*N]
   int32_t npatch = 0;
   std::vector<int32_t> launch_first, launch_count;
+  // two halves of the interior on two streams (PatchPlan::launch_stream): the second stream and its fork / order /
+  // join events
+  std::vector<int8_t> launch_stream;
+  int launch_signal = -1, launch_wait = -1;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_order = nullptr, ev_join = nullptr;
   std::vector<int32_t> pcell_h, pncell_h; // host copies for components that share the patches
   long long npdofs = 0;
   int max_m = 0;
@@ -1663,6 +1669,33 @@ int launch_stiffness(pmg_laplacian op, const double* x, double* y, int first, in
   return PMG_OK;
 }
 
+// one launch of the stiffness kernel over patches [first, first + count)
+static int launch_patches(pmg_laplacian op, const double* x, double* y, int first, int count, int atomic_out,
+                          hipStream_t s)
+{
+  switch (op->P)
+  {
+  case 1:
+    return launch_stiffness<1>(op, x, y, first, count, atomic_out, s);
+  case 2:
+    return launch_stiffness<2>(op, x, y, first, count, atomic_out, s);
+  case 3:
+    return launch_stiffness<3>(op, x, y, first, count, atomic_out, s);
+  case 4:
+    return launch_stiffness<4>(op, x, y, first, count, atomic_out, s);
+  case 5:
+    return launch_stiffness<5>(op, x, y, first, count, atomic_out, s);
+  case 6:
+    return launch_stiffness<6>(op, x, y, first, count, atomic_out, s);
+  case 7:
+    return launch_stiffness<7>(op, x, y, first, count, atomic_out, s);
+  case 8:
+    return launch_stiffness<8>(op, x, y, first, count, atomic_out, s);
+  default:
+    return fail(PMG_ERR_INVALID, "Unsupported degree"); // src/laplacian.hpp:346,479
+  }
+}
+
 // launches [l0, l1) of the plan, in stream order
 int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, hipStream_t s)
 {
@@ -1679,10 +1712,37 @@ int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, h
     }
     PMG_HIP(hipEventRecord(op->prof_events[op->prof_used], s));
   }
+  // Two halves of the interior: the launches of the second half go to the operator's second stream, forked from and
+  // joined to `s` with events (inside a stream capture these become two branches of the graph).  One ordering event
+  // between the halves: patches.hip.
+  const bool two = !op->launch_stream.empty() && l0 == 0 && l1 >= op->n_launch_l && l1 > l0 && op->batch_patches == 0;
+  if (two)
+  {
+    PMG_HIP(hipEventRecord(op->ev_fork, s));
+    PMG_HIP(hipStreamWaitEvent(op->stream2, op->ev_fork, 0));
+  }
+  auto join = [&]() -> int {
+    PMG_HIP(hipEventRecord(op->ev_join, op->stream2));
+    PMG_HIP(hipStreamWaitEvent(s, op->ev_join, 0));
+    return PMG_OK;
+  };
+#ifdef PMG_ABL_OFFSET // timing only (the deferred patches run out of order): the second half's launch boundaries
+                      // shifted by half a launch against the first half's
+  int def_first[2] = {0, 0}, def_count[2] = {0, 0};
+#endif
   for (int l = l0; l < l1; ++l)
   {
     int first = op->launch_first[l], count = op->launch_count[l];
     const int atomic_out = (l >= op->n_plain) ? 1 : 0; // merged launches add with atomics
+    hipStream_t sl = s;
+    if (two && l < op->n_launch_l)
+    {
+      if (l == op->launch_wait)
+        PMG_HIP(hipStreamWaitEvent(s, op->ev_order, 0));
+      sl = op->launch_stream[l] ? op->stream2 : s;
+    }
+    if (two && l == op->n_launch_l)
+      PMG_TRY(join());
 #ifdef PMG_ABL_ONE_LAUNCH // timing only (wrong sums on shared dofs): all colours of a cell list in one launch -- what do
                           // the seven launch boundaries cost?  (profiles/kernel_tuning_r03.md section 14)
     if (!atomic_out)
@@ -1690,42 +1750,39 @@ int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, h
              && op->launch_first[l + 1] == first + count)
         count += op->launch_count[++l];
 #endif
-    switch (op->P)
+#ifdef PMG_ABL_OFFSET
+    if (two && (l == 1 || l == op->launch_signal + 2) && l < op->n_launch_l)
     {
-    case 1:
-      PMG_TRY(launch_stiffness<1>(op, x, y, first, count, atomic_out, s));
-      break;
-    case 2:
-      PMG_TRY(launch_stiffness<2>(op, x, y, first, count, atomic_out, s));
-      break;
-    case 3:
-      PMG_TRY(launch_stiffness<3>(op, x, y, first, count, atomic_out, s));
-      break;
-    case 4:
-      PMG_TRY(launch_stiffness<4>(op, x, y, first, count, atomic_out, s));
-      break;
-    case 5:
-      PMG_TRY(launch_stiffness<5>(op, x, y, first, count, atomic_out, s));
-      break;
-    case 6:
-      PMG_TRY(launch_stiffness<6>(op, x, y, first, count, atomic_out, s));
-      break;
-    case 7:
-      PMG_TRY(launch_stiffness<7>(op, x, y, first, count, atomic_out, s));
-      break;
-    case 8:
-      PMG_TRY(launch_stiffness<8>(op, x, y, first, count, atomic_out, s));
-      break;
-    default:
-      return fail(PMG_ERR_INVALID, "Unsupported degree"); // src/laplacian.hpp:346,479
+      const int k = l == 1 ? 0 : 1;
+      def_first[k] = first + count / 2;
+      def_count[k] = count - count / 2;
+      count = count / 2;
+    }
+#endif
+    if (count > 0)
+      PMG_TRY(launch_patches(op, x, y, first, count, atomic_out, sl));
+    if (two && l == op->launch_signal)
+    {
+#ifdef PMG_ABL_OFFSET
+      if (def_count[0] > 0)
+        PMG_TRY(launch_patches(op, x, y, def_first[0], def_count[0], 0, op->stream2));
+#endif
+      PMG_HIP(hipEventRecord(op->ev_order, op->stream2));
     }
   }
+#ifdef PMG_ABL_OFFSET
+  if (two && def_count[1] > 0)
+    PMG_TRY(launch_patches(op, x, y, def_first[1], def_count[1], 0, op->stream2));
+#endif
+  if (two && l1 == op->n_launch_l)
+    PMG_TRY(join());
   PMG_HIP(hipGetLastError());
   if (prof)
   {
     PMG_HIP(hipEventRecord(op->prof_events[op->prof_used + 1], s));
     op->prof_used += 2;
-    op->prof_launches += l1 - l0;
+    for (int l = l0; l < l1; ++l)
+      op->prof_launches += op->launch_count[l] > 0;
   }
   return PMG_OK;
 }
@@ -2028,6 +2085,16 @@ extern "C" int pmg_laplacian_create_ordered(
   op->launch_count = plan.launch_count;
   op->n_launch_l = plan.n_launch_l;
   op->n_plain = plan.n_plain;
+  op->launch_stream = plan.launch_stream;
+  op->launch_signal = plan.launch_signal;
+  op->launch_wait = plan.launch_wait;
+  if (!op->launch_stream.empty())
+  {
+    PMG_HIP(hipStreamCreateWithFlags(&op->stream2, hipStreamNonBlocking));
+    PMG_HIP(hipEventCreateWithFlags(&op->ev_fork, hipEventDisableTiming));
+    PMG_HIP(hipEventCreateWithFlags(&op->ev_order, hipEventDisableTiming));
+    PMG_HIP(hipEventCreateWithFlags(&op->ev_join, hipEventDisableTiming));
+  }
   PMG_TRY(upload(&op->pcell, plan.pcell.data(), plan.pcell.size(), s));
   PMG_TRY(upload(&op->pncell, plan.pncell.data(), plan.pncell.size(), s));
   op->n_bzero = (int32_t)plan.bzero.size();
@@ -2110,6 +2177,11 @@ extern "C" int pmg_laplacian_destroy(pmg_laplacian op)
   (void)hipFree(op->diag_inv);
   for (hipEvent_t e : op->prof_events)
     (void)hipEventDestroy(e);
+  for (hipEvent_t e : {op->ev_fork, op->ev_order, op->ev_join})
+    if (e)
+      (void)hipEventDestroy(e);
+  if (op->stream2)
+    (void)hipStreamDestroy(op->stream2);
   if (op->ev0)
     (void)hipEventDestroy(op->ev0);
   if (op->ev1)
@@ -2237,7 +2309,7 @@ extern "C" int pmg_laplacian_time_kernel(pmg_laplacian op, const double* in, dou
   PMG_HIP(hipEventSynchronize(op->ev1));
   float ms = 0.f;
   PMG_HIP(hipEventElapsedTime(&ms, op->ev0, op->ev1));
-  *ms_per_launch = (double)ms / reps / nl;
+  *ms_per_launch = (double)ms / reps / pmg_laplacian_launches_per_apply(op);
   return PMG_OK;
 }
 
@@ -2309,6 +2381,17 @@ extern "C" int pmg_laplacian_read_profile(pmg_laplacian op, double* total_ms, lo
 // number of stiffness-kernel launches one operator application issues
 extern "C" int pmg_laplacian_launches_per_apply(pmg_laplacian op)
 {
-  return op ? (int)op->launch_first.size() : -1;
+  if (!op)
+    return -1;
+  int n = 0;
+  for (int32_t c : op->launch_count)
+    n += c > 0;
+  return n;
+}
+
+// 2 if the interior launches of an application run as two halves on two streams, else 1
+extern "C" int pmg_laplacian_apply_streams(pmg_laplacian op)
+{
+  return !op ? -1 : (!op->launch_stream.empty() && op->batch_patches == 0) ? 2 : 1;
 }
 

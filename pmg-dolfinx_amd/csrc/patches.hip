@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -182,6 +183,7 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
     std::vector<uint16_t> lmap;
     int colour = 0;
     int launch = 0;
+    int part = 0; // interior set only: 0 / 1 = first / second half (own stream), 2 = separator (joins the boundary set)
   };
   std::vector<Tmp> tmp;
   int set_first[3] = {0, 0, 0};
@@ -251,6 +253,64 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
     plan.max_M = std::max(plan.max_M, (int)t.dofs.size());
   }
 
+  // ---- two halves of the interior, one per stream (see PatchPlan::launch_stream) ----
+  // OFF unless PMG_APPLY_STREAMS=1 (levels of >= 2048 interior patches whose colours are launched one by one) or =2
+  // (small levels too: tests).  Measured, round 4 (profiles/kernel_tuning_r04.md): two INDEPENDENT half-size operators
+  // on two streams take 8 % less than back to back -- each fills the other's launch tails -- but inside one operator
+  // the fork, the ordering event and the join cost more than that: 440 against 431 us at degree 4, 64^3; 614 against
+  // 585 at degree 2, 128^3; the same inside a replayed graph.
+  bool split = false;
+  {
+    const char* e = std::getenv("PMG_APPLY_STREAMS");
+    const bool allowed = e && (e[0] == '1' || e[0] == '2');
+    long long interior_pdofs = 0;
+    for (int p = set_first[0]; p < set_first[1]; ++p)
+      interior_pdofs += (long long)tmp[p].dofs.size();
+    const long long merge_below = g_merge_below >= 0 ? g_merge_below : (long long)(P <= 1 ? 2 : 6) << 20;
+    const int ni = set_first[1] - set_first[0];
+    const int min_patches = e && e[0] == '2' ? 16 : 2048;
+    if (allowed && interior_pdofs > merge_below && ni >= min_patches)
+    {
+      // cut at the middle patch position along the axis with the most distinct positions
+      std::vector<float> pc[3];
+      for (int a = 0; a < 3; ++a)
+        pc[a].resize(ni);
+      for (int p = 0; p < ni; ++p)
+        for (int a = 0; a < 3; ++a)
+        {
+          double v = 0;
+          for (int32_t c : tmp[set_first[0] + p].cells)
+            v += centroid[3 * (size_t)c + a];
+          pc[a][p] = (float)(v / (double)tmp[set_first[0] + p].cells.size());
+        }
+      int best = -1, best_n = 0;
+      float cut = 0.f;
+      for (int a = 0; a < 3; ++a)
+      {
+        std::vector<float> u(pc[a]);
+        std::sort(u.begin(), u.end());
+        const float ext = std::max(u.back() - u.front(), 1e-30f);
+        std::vector<float> d;
+        for (float v : u)
+          if (d.empty() || v - d.back() > 1e-4f * ext)
+            d.push_back(v);
+        if ((int)d.size() > best_n)
+        {
+          best_n = (int)d.size();
+          best = a;
+          cut = d.size() > 1 ? 0.5f * (d[d.size() / 2 - 1] + d[d.size() / 2]) : d[0];
+        }
+      }
+      if (best >= 0 && best_n >= 4)
+      {
+        int n1 = 0;
+        for (int p = 0; p < ni; ++p)
+          n1 += (tmp[set_first[0] + p].part = pc[best][p] < cut ? 0 : 1);
+        split = n1 > 0 && n1 < ni;
+      }
+    }
+  }
+
   // greedy colouring per set: a patch takes the lowest colour none of its dofs has seen
   std::vector<int> ncolours(2, 0);
   {
@@ -275,11 +335,71 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
       }
     }
   }
-  // launch index = position in stream order: lcells colours, then bcells colours
-  for (int p = 0; p < np; ++p)
-    tmp[p].launch = (p < set_first[1] ? 0 : ncolours[0]) + tmp[p].colour;
-  const int nlaunch = ncolours[0] + ncolours[1];
-  plan.n_launch_l = ncolours[0];
+  // The two halves meet in a layer of patches on either side of the cut.  The second half launches the colours of ITS
+  // layer first, the first half the colours of its layer last, and the first of those waits (an event) for the last of
+  // the others: every shared dof is then touched by the second half strictly before the first half, which is the order
+  // the launch indices (and with them the PD_ACC flags) state.  On a tensor grid the two layers have opposite parity
+  // along the cut axis, i.e. disjoint colours, and the wait sits in the middle of both sequences; if the colouring does
+  // not separate them that way (kb >= ka below), the level keeps the single sequence.
+  std::vector<int> seq[2]; // colours of each half in launch order
+  int ka = 0, kb = -1;
+  if (split)
+  {
+    std::vector<char> in_part[2] = {std::vector<char>(ndofs, 0), std::vector<char>(ndofs, 0)};
+    for (int p = set_first[0]; p < set_first[1]; ++p)
+      for (int32_t d : tmp[p].dofs)
+        in_part[tmp[p].part][d] = 1;
+    std::vector<char> present[2] = {std::vector<char>(ncolours[0], 0), std::vector<char>(ncolours[0], 0)};
+    std::vector<char> edge[2] = {std::vector<char>(ncolours[0], 0), std::vector<char>(ncolours[0], 0)};
+    for (int p = set_first[0]; p < set_first[1]; ++p)
+    {
+      const int h = tmp[p].part;
+      present[h][tmp[p].colour] = 1;
+      for (int32_t d : tmp[p].dofs)
+        if (in_part[1 - h][d])
+        {
+          edge[h][tmp[p].colour] = 1;
+          break;
+        }
+    }
+    for (int c = 0; c < ncolours[0]; ++c) // first half: colours without layer patches first
+      if (present[0][c] && !edge[0][c])
+        seq[0].push_back(c);
+    ka = (int)seq[0].size();
+    for (int c = 0; c < ncolours[0]; ++c)
+      if (present[0][c] && edge[0][c])
+        seq[0].push_back(c);
+    for (int c = 0; c < ncolours[0]; ++c) // second half: colours with layer patches first
+      if (present[1][c] && edge[1][c])
+        seq[1].push_back(c);
+    kb = (int)seq[1].size() - 1;
+    for (int c = 0; c < ncolours[0]; ++c)
+      if (present[1][c] && !edge[1][c])
+        seq[1].push_back(c);
+    if (kb >= ka || kb < 0)
+      split = false;
+  }
+  // launch index = position in stream order: lcells colours (two halves: position q of the first half, position q of
+  // the second half, position q + 1 ...; a half that has run out of colours leaves empty launches), then bcells colours
+  int nl_interior = ncolours[0];
+  if (split)
+  {
+    const int nq = (int)std::max(seq[0].size(), seq[1].size());
+    nl_interior = 2 * nq;
+    std::vector<int> pos[2] = {std::vector<int>(ncolours[0], 0), std::vector<int>(ncolours[0], 0)};
+    for (int h = 0; h < 2; ++h)
+      for (size_t q = 0; q < seq[h].size(); ++q)
+        pos[h][seq[h][q]] = (int)q;
+    for (int p = set_first[0]; p < set_first[1]; ++p)
+      tmp[p].launch = 2 * pos[tmp[p].part][tmp[p].colour] + tmp[p].part;
+  }
+  else
+    for (int p = set_first[0]; p < set_first[1]; ++p)
+      tmp[p].launch = tmp[p].colour;
+  for (int p = set_first[1]; p < np; ++p)
+    tmp[p].launch = nl_interior + tmp[p].colour;
+  const int nlaunch = nl_interior + ncolours[1];
+  plan.n_launch_l = nl_interior;
   std::vector<int32_t> order(np);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(),
@@ -346,7 +466,7 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
   // 206 -> 219, 64^3 427 -> 570; P=6 24^3 141 -> 94; P=8 16^3 174 -> 73.  Hence the
   // thresholds below, in patch dofs (= atomically added values) of the interior list.
   {
-    const int nl = ncolours[0];
+    const int nl = nl_interior;
     const int32_t bfirst = nl < nlaunch ? plan.launch_first[nl] : np;
     const long long interior_pdofs = plan.poff[bfirst];
     const long long merge_below = g_merge_below >= 0 ? g_merge_below : (long long)(P <= 1 ? 2 : 6) << 20;
@@ -373,6 +493,14 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
     }
     plan.launch_first = lf;
     plan.launch_count = lc;
+    if (split && !merge_interior)
+    {
+      plan.launch_stream.assign(lf.size(), 0);
+      for (int l = 0; l < nl; ++l)
+        plan.launch_stream[l] = (int8_t)(l % 2);
+      plan.launch_signal = 2 * kb + 1; // the second half's last launch with layer patches ...
+      plan.launch_wait = 2 * ka;       // ... must be complete before this launch of the first half starts
+    }
     // dofs whose first writer is an atomic launch must be zero beforehand
     const int first_atomic_colour = merge_interior ? 0 : nl;
     for (int32_t d = 0; d < ndofs; ++d)

@@ -118,6 +118,12 @@ struct PatchPlan
   std::vector<int32_t> launch_first, launch_count;
   int n_launch_l = 0;
   int n_plain = 0; // the first n_plain launches store (colours); the rest add with atomics
+  // Two halves of the interior on two streams (round 4): launch_stream[l] = 1 for the launches of the second half
+  // (empty = everything on the caller's stream), so that each half fills the other's launch tails.  The halves share
+  // dofs only across the cut; launch `launch_wait` (first half) must not start before launch `launch_signal` (second
+  // half) is complete, which orders every shared dof as the launch indices say (patches.hip).
+  std::vector<int8_t> launch_stream;
+  int launch_signal = -1, launch_wait = -1;
   int max_M = 0;
   // The boundary cell list is a thin shell: its colours would be many small
   // launches.  They are issued as ONE launch whose patches add their sums to y

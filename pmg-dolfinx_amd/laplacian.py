@@ -157,6 +157,10 @@ class MatFreeLaplacian:
     def launches_per_apply(self) -> int:
         return call("pmg_laplacian_launches_per_apply", self._handle)
 
+    def apply_streams(self) -> int:
+        """2 if the interior colour launches run as two halves on two streams (include/pmg_amd.h), else 1."""
+        return call("pmg_laplacian_apply_streams", self._handle)
+
     def time_kernel(self, x: Vector, y: Vector, reps: int) -> float:
         """Mean milliseconds of one stiffness-kernel launch (one patch colour);
         an operator application issues ``launches_per_apply()`` of them (HIP

@@ -773,3 +773,67 @@ def test_merged_and_coloured_launches_agree(pm, P, n):
     # no global atomics on the coloured path; inside a patch the cell sums meet in LDS in whatever
     # order the wavefronts arrive, so two runs agree to rounding, not bit for bit
     assert _relerr(got["coloured"][0], got["coloured"][2]) < 1e-14
+
+
+# the interior of a large level runs as two halves on two streams (include/pmg_amd.h, pmg_laplacian_apply_streams);
+# PMG_APPLY_STREAMS=2 asks for that on the small meshes a test can check against the oracle
+@pytest.mark.parametrize("P,n,shuffle", [(1, (16, 8, 32), False), (2, (16, 8, 32), False), (3, (8, 8, 32), False),
+                                         (4, (8, 6, 32), False), (4, (6, 12, 16), False), (6, (4, 4, 32), False),
+                                         (8, (8, 2, 12), False), (4, (8, 4, 16), True), (2, (8, 8, 32), True)])
+def test_two_stream_halves_agree_with_oracle(pm, P, n, shuffle, monkeypatch):
+    """Coloured launches split into two halves on two streams: same vector as the oracle, twice in a row (the event
+    that orders the dofs along the cut), under a stream capture as well; a mesh whose cells arrive in random order
+    (patches from Morton chunks, colours that do not separate the two sides of the cut) falls back to one sequence or
+    splits -- either way the result is the oracle's."""
+    from oracle import c_oracle as co
+
+    # (a separable stretch keeps the centroids on a tensor grid, which is what makes tensor-block patches; the
+    # shuffled cases use the twisted mesh, whose patches are Morton chunks)
+    part = pm.BoxPartition(n, warp=twist if shuffle else (lambda x: x + 0.05 * np.sin(2.0 * np.pi * x)))
+    lv = part.level(P)
+    layout = pm.make_layout(lv)
+    lcells = lv.lcells
+    if shuffle:
+        lcells = np.ascontiguousarray(np.random.default_rng(5).permutation(lcells))
+    A = co.CLevel(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.bc_marker)
+    u = np.random.default_rng(11).standard_normal(lv.ndofs)
+    x = _vec(pm, layout, u)
+    ref = A.apply(u)
+    monkeypatch.setenv("PMG_APPLY_STREAMS", "2")
+    try:
+        pm.set_merge_threshold(0)
+        op = pm.MatFreeLaplacian(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lcells, lv.bcells, lv.bc_marker,
+                                 layout)
+        monkeypatch.setenv("PMG_APPLY_STREAMS", "0")
+        one = pm.MatFreeLaplacian(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lcells, lv.bcells, lv.bc_marker,
+                                  layout)
+    finally:
+        pm.set_merge_threshold(-1)
+    assert one.apply_streams() == 1
+    if not shuffle:
+        assert op.apply_streams() == 2
+    y = pm.Vector(layout)
+    for rep in range(3):
+        y.set(float(rep))
+        op(x, y)
+        assert _relerr(y.data_copy(), ref) < 1e-12, rep
+    # captured: the fork / join become two branches of the graph
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        op(x, y)
+        g = torch.cuda.CUDAGraph()
+        y.set(-1.0)
+        with torch.cuda.graph(g, stream=s):
+            op(x, y)
+        y.set(5.0)
+        g.replay()
+        g.replay()
+    torch.cuda.synchronize()
+    assert _relerr(y.data_copy(), ref) < 1e-12
+    # diagonal and transfers built on the same patches
+    op.compute_diag_inverse()
+    one.compute_diag_inverse()
+    d2, d1 = pm.Vector(layout), pm.Vector(layout)
+    op.get_diag_inverse(d2)
+    one.get_diag_inverse(d1)
+    assert _relerr(d2.data_copy(), d1.data_copy()) < 1e-13
