@@ -165,6 +165,12 @@ bool comm_capture_ready(pmg_layout l, bool with_allreduce);
 // window.hip -- the exchange of a layout that has halo windows (x: the whole vector, owned entries first)
 int window_exchange_begin(pmg_layout l, bool reverse, const double* x, hipStream_t s);
 int window_exchange_end(pmg_layout l, bool reverse, double* x, hipStream_t s);
+int window_exchange_whole(pmg_layout l, double* x, hipStream_t s);
+// owner -> ghost exchange of x, complete on return of the stream: one launch on a window layout, begin + end otherwise
+int scatter_fwd_whole(pmg_layout l, double* x, hipStream_t s);
+// is the exchange of this layout one that a small level should take whole, in front of ONE launch over all its cells,
+// rather than split around the interior cells' launch?  (halo windows; PMG_FUSED_EXCHANGE=0 in the environment: never)
+bool layout_exchanges_whole(pmg_layout l);
 void window_destroy(pmg_layout l);
 // ... and the reductions / set-up gathers of a communicator made of windows
 int wcomm_allreduce(pmg_comm c, double* d_values, int n, bool max, hipStream_t s);

@@ -604,6 +604,12 @@ TransferArgs make_args(pmg_interpolator ip, int first)
   return A;
 }
 
+// the fine operator is a small level's (all launches merged) and the layout's exchange is one launch
+bool whole_exchange(pmg_interpolator ip, pmg_layout l)
+{
+  return ip->fv.merged && l->num_ghosts > 0 && layout_exchanges_whole(l);
+}
+
 // patches of the interior cell list come first in launch order
 int interior_patches(pmg_interpolator ip)
 {
@@ -614,6 +620,15 @@ int interior_patches(pmg_interpolator ip)
 int prolong_patched(pmg_interpolator ip, double* coarse, double* fine, int add, hipStream_t s)
 {
   const int n_int = interior_patches(ip), n_all = ip->fv.npatch;
+  if (whole_exchange(ip, ip->lc)) // a small level: the exchange whole, then all patches in one launch (laplacian.hip)
+  {
+    PMG_TRY(scatter_fwd_whole(ip->lc, coarse, s));
+    if (n_all > 0)
+      PMG_TRY(launch_prolong_patch(ip->ndc, ip->ndf, n_all, ip->pwaves * 64, ip->pshm, s, make_args(ip, 0), coarse,
+                                   fine, add));
+    PMG_HIP(hipGetLastError());
+    return PMG_OK;
+  }
   PMG_TRY(pmg_scatter_fwd_begin(ip->lc, coarse, (pmg_stream)s)); // src/interpolate.hpp:202
   if (n_int > 0)
     PMG_TRY(launch_prolong_patch(ip->ndc, ip->ndf, n_int, ip->pwaves * 64, ip->pshm, s, make_args(ip, 0),
@@ -636,6 +651,16 @@ int restrict_patched(pmg_interpolator ip, double* fine, const double* fine_sub, 
   // fine_sub (optional, layouts without ghosts only): restrict fine - fine_sub.
   const int n_int = interior_patches(ip), n_all = ip->fv.npatch;
   PMG_REQUIRE(!fine_sub || ip->lf->num_ghosts == 0, "restriction of a difference needs a layout without ghosts");
+  if (whole_exchange(ip, ip->lf))
+  {
+    PMG_TRY(scatter_fwd_whole(ip->lf, fine, s));
+    launch_zero(ip->lc->total(), coarse, s);
+    if (n_all > 0)
+      PMG_TRY(launch_restrict_patch(ip->ndc, ip->ndf, n_all, ip->pwaves * 64, ip->pshm, s, make_args(ip, 0), fine,
+                                    fine_sub, coarse, 1));
+    PMG_HIP(hipGetLastError());
+    return PMG_OK;
+  }
   PMG_TRY(pmg_scatter_fwd_begin(ip->lf, fine, (pmg_stream)s));             // :264
   launch_zero(ip->lc->total(), coarse, s); // :270
   if (n_int > 0)

@@ -1721,6 +1721,7 @@ int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, h
     PMG_HIP(hipEventRecord(op->ev_fork, s));
     PMG_HIP(hipStreamWaitEvent(op->stream2, op->ev_fork, 0));
   }
+  int issued = 0;
   auto join = [&]() -> int {
     PMG_HIP(hipEventRecord(op->ev_join, op->stream2));
     PMG_HIP(hipStreamWaitEvent(s, op->ev_join, 0));
@@ -1759,8 +1760,14 @@ int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, h
       count = count / 2;
     }
 #endif
+    // consecutive atomic launches over contiguous patches that the caller asked for together: one launch
+    while (atomic_out && l + 1 < l1 && op->launch_first[l + 1] == first + count && !two && op->batch_patches == 0)
+      count += op->launch_count[++l];
     if (count > 0)
+    {
       PMG_TRY(launch_patches(op, x, y, first, count, atomic_out, sl));
+      ++issued;
+    }
     if (two && l == op->launch_signal)
     {
 #ifdef PMG_ABL_OFFSET
@@ -1781,8 +1788,7 @@ int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, h
   {
     PMG_HIP(hipEventRecord(op->prof_events[op->prof_used + 1], s));
     op->prof_used += 2;
-    for (int l = l0; l < l1; ++l)
-      op->prof_launches += op->launch_count[l] > 0;
+    op->prof_launches += issued;
   }
   return PMG_OK;
 }
@@ -1838,6 +1844,7 @@ PatchView laplacian_patches(pmg_laplacian op)
   v.launch_first = &op->launch_first;
   v.launch_count = &op->launch_count;
   v.n_launch_l = op->n_launch_l;
+  v.merged = op->n_plain == 0;
   v.pcell = op->pcell;
   v.pncell = op->pncell;
   v.poff = op->poff;
@@ -1857,6 +1864,15 @@ static bool zero_fills_output(pmg_laplacian op)
 }
 bool laplacian_wants_zeroed_output(pmg_laplacian op) { return zero_fills_output(op); }
 
+// Interior and boundary patches in ONE launch behind a whole exchange?  Only where both lists add with atomics
+// anyway (n_plain == 0: the merged form of a small level), the geometry is resident, and the layout's exchange is one
+// launch (halo windows).  The transfers of the level follow the operator (interpolate.hip).
+bool laplacian_single_launch(pmg_laplacian op)
+{
+  return op->n_plain == 0 && op->batch_patches == 0 && (int)op->launch_first.size() == 2
+         && op->launch_first[1] == op->launch_first[0] + op->launch_count[0] && layout_exchanges_whole(op->layout);
+}
+
 // operator()(in, out), src/laplacian.hpp:462-482 + impl_operator :373-460
 static int apply_impl(pmg_laplacian op, double* in, double* out, bool out_is_zero, hipStream_t s,
                       bool exchange = true)
@@ -1871,6 +1887,17 @@ static int apply_impl(pmg_laplacian op, double* in, double* out, bool out_is_zer
   if (op->n_bzero > 0 && !zero_all)
     zero_list_kernel<<<(op->n_bzero + 255) / 256 > 1024 ? 1024 : (op->n_bzero + 255) / 256, 256, 0, s>>>(
         op->n_bzero, op->bzero, out);
+  // A small level (every launch adds with atomics: the merged form) on a window layout: the exchange whole, in one
+  // launch, then ALL patches in one launch -- two launches instead of four; there is nothing an interior launch of a
+  // few microseconds could hide (laplacian_single_launch).
+  if (laplacian_single_launch(op))
+  {
+    if (exchange)
+      PMG_TRY(scatter_fwd_whole(l, in, s));
+    PMG_TRY(run_launches(op, in, out, 0, nl, s));
+    op->applies++;
+    return PMG_OK;
+  }
   if (exchange)
     PMG_TRY(pmg_scatter_fwd_begin(l, in, (pmg_stream)s));        // :378
   PMG_TRY(run_launches(op, in, out, 0, op->n_launch_l, s));      // :380-413 interior cells

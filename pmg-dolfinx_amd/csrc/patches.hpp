@@ -144,6 +144,7 @@ struct PatchView
   const std::vector<int32_t>* launch_first = nullptr;
   const std::vector<int32_t>* launch_count = nullptr;
   int n_launch_l = 0;
+  bool merged = false; // the operator's launches all add with atomics (a small level: PatchPlan::n_plain == 0)
   // device arrays
   const int32_t* pcell = nullptr;
   const int32_t* pncell = nullptr;

@@ -862,6 +862,27 @@ extern "C" int pmg_scatter_fwd_end(pmg_layout l, double* x, pmg_stream stream)
   return PMG_OK;
 }
 
+namespace pmg
+{
+int scatter_fwd_whole(pmg_layout l, double* x, hipStream_t s)
+{
+  if (l->win)
+  {
+    l->fwd_scatters++;
+    return window_exchange_whole(l, x, s);
+  }
+  PMG_TRY(pmg_scatter_fwd_begin(l, x, (pmg_stream)s));
+  return pmg_scatter_fwd_end(l, x, (pmg_stream)s);
+}
+bool layout_exchanges_whole(pmg_layout l)
+{
+  if (!l->win)
+    return false;
+  const char* e = std::getenv("PMG_FUSED_EXCHANGE");
+  return !(e && e[0] == '0');
+}
+} // namespace pmg
+
 // src/vector.hpp:249-267: ghosts are packed into the *recv* buffer and travel
 // back to their owners, who receive them in the *send* buffer.
 extern "C" int pmg_scatter_rev_begin(pmg_layout l, const double* x, pmg_stream stream)

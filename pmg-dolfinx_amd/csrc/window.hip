@@ -104,9 +104,9 @@ __device__ inline bool wait_flag(const uint64_t* p, uint64_t target, long long l
 
 // in[idx[i]] -> dst[slot][i], the entry's place in its neighbour's window (forward: the send list over the owned
 // entries; reverse: the receive list over the ghost entries, `in` already offset)
-__global__ void window_put_kernel(const WindowDev* __restrict__ wp, int d, int n,
-                                  const int32_t* __restrict__ idx, double* const* __restrict__ dst,
-                                  const double* __restrict__ in)
+__device__ __forceinline__ void window_put_body(const WindowDev* __restrict__ wp, int d, int n,
+                                                const int32_t* __restrict__ idx, double* const* __restrict__ dst,
+                                                const double* __restrict__ in)
 {
   const WindowDev& w = *wp;
   __shared__ uint64_t s_seq;
@@ -155,11 +155,18 @@ __global__ void window_put_kernel(const WindowDev* __restrict__ wp, int d, int n
   }
 }
 
+__global__ void window_put_kernel(const WindowDev* __restrict__ wp, int d, int n,
+                                  const int32_t* __restrict__ idx, double* const* __restrict__ dst,
+                                  const double* __restrict__ in)
+{
+  window_put_body(wp, d, n, idx, dst, in);
+}
+
 // my window -> out[idx[i]] (assign: ghosts; add: owned entries)
 template <bool ADD>
-__global__ void window_get_kernel(const WindowDev* __restrict__ wp, int d, int n,
-                                  const int32_t* __restrict__ idx, const int32_t* __restrict__ pos,
-                                  double* __restrict__ out)
+__device__ __forceinline__ void window_get_body(const WindowDev* __restrict__ wp, int d, int n,
+                                                const int32_t* __restrict__ idx, const int32_t* __restrict__ pos,
+                                                double* __restrict__ out)
 {
   const WindowDev& w = *wp;
   __shared__ uint64_t s_seq;
@@ -203,6 +210,31 @@ __global__ void window_get_kernel(const WindowDev* __restrict__ wp, int d, int n
       __hip_atomic_store(&local[L_GOT + d], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+template <bool ADD>
+__global__ void window_get_kernel(const WindowDev* __restrict__ wp, int d, int n,
+                                  const int32_t* __restrict__ idx, const int32_t* __restrict__ pos,
+                                  double* __restrict__ out)
+{
+  window_get_body<ADD>(wp, d, n, idx, pos, out);
+}
+
+// The whole owner -> ghost exchange in ONE launch (round 4): every block puts its share, then waits for the
+// neighbours' data and unpacks its share.  For levels so small that a kernel is shorter than the gap between two
+// dependent launches (config 3's per-GPU share: 32^3 cells), where putting before and getting behind the interior
+// cells' launch hides nothing and costs a launch.  All blocks of the grid are resident together (put_blocks() <= 128),
+// so a block that polls never keeps a block that still has to put from running -- on this rank; between ranks every
+// rank puts before it polls.
+__global__ void window_exchange_kernel(const WindowDev* __restrict__ wp, int n_send,
+                                       const int32_t* __restrict__ send_idx, double* const* __restrict__ dst,
+                                       const double* __restrict__ in, int n_recv,
+                                       const int32_t* __restrict__ recv_idx, const int32_t* __restrict__ recv_pos,
+                                       double* __restrict__ ghosts)
+{
+  window_put_body(wp, 0, n_send, send_idx, dst, in);
+  __syncthreads();
+  window_get_body<false>(wp, 0, n_recv, recv_idx, recv_pos, ghosts);
 }
 
 constexpr size_t ALIGN = 32; // doubles: every neighbour's segment starts on a 256-byte boundary
@@ -280,6 +312,20 @@ int window_exchange_begin(pmg_layout l, bool reverse, const double* x, hipStream
   window_put_kernel<<<put_blocks(n), PUT_THREADS, 0, s>>>(w->dev, d, n, reverse ? l->recv_idx : l->send_idx,
                                                           reverse ? w->rev_dst : w->fwd_dst,
                                                           reverse ? x + l->size_local : x);
+  PMG_HIP(hipGetLastError());
+  return PMG_OK;
+}
+
+// owner -> ghost, begin and end in one launch (window_exchange_kernel)
+int window_exchange_whole(pmg_layout l, double* x, hipStream_t s)
+{
+  pmg_window_s* w = l->win;
+  PMG_TRY(window_check(l));
+  if (w->host.n == 0)
+    return PMG_OK;
+  const int blocks = std::max(put_blocks(l->n_send), put_blocks(l->n_recv));
+  window_exchange_kernel<<<blocks, PUT_THREADS, 0, s>>>(w->dev, l->n_send, l->send_idx, w->fwd_dst, x, l->n_recv,
+                                                        l->recv_idx, w->recv_pos, x + l->size_local);
   PMG_HIP(hipGetLastError());
   return PMG_OK;
 }

@@ -259,6 +259,9 @@ def _worker_body(rank, world, port, n, dims, orders, halo="exchange"):
         import pmg_dolfinx_amd as pm
 
         torch.cuda.set_device(0)
+        if halo == "windows-split":  # small levels as large ones: put, interior cells, get, boundary cells
+            os.environ["PMG_FUSED_EXCHANGE"] = "0"
+            halo = "windows"
         comm = {"windows": lambda: pm.TorchComm(halo="windows"),       # halo windows, reductions on the gloo callbacks
                 "window-comm": lambda: pm.WindowComm.from_torch(),     # halo AND reductions through windows
                 "exchange": lambda: None}[halo]()
@@ -330,7 +333,7 @@ def test_ranks_share_one_gpu(dims, n, built):
     _assert_rank_results(_run_ranks(_worker, world, (n, dims, orders)))
 
 
-@pytest.mark.parametrize("route", ["windows", "window-comm"])
+@pytest.mark.parametrize("route", ["windows", "window-comm", "windows-split"])
 @pytest.mark.parametrize("dims,n", [((1, 1, 2), (3, 4, 8)), ((1, 2, 2), (3, 4, 6)),
                                     ((1, 1, 3), (3, 4, 9))])  # a chain: the middle rank has two neighbours, the ends
                                                                # one -- a rank's place in its neighbours' lists differs
@@ -340,7 +343,9 @@ def test_ranks_share_one_gpu_through_halo_windows(dims, n, route, built):
     window.hip between real processes (two and four: the box admits six on its GPU, the test runner included), with the one GPU standing in for the
     peers' GPUs.  route "windows": the reductions stay on the gloo callbacks; "window-comm": the library's communicator
     made of windows -- no transport library at all, every reduction (the dot products of CG, the sums of whole level
-    vectors in the replicated coarse solve: chunked) two kernels of direct stores and flags.  Not run with the ranks as threads of one process: eight
+    vectors in the replicated coarse solve: chunked) two kernels of direct stores and flags; "windows-split": the levels
+    of these small meshes take their exchange whole, in one launch in front of one launch over all cells (round 4,
+    laplacian_single_launch) -- this route runs them the way a large level runs, PMG_FUSED_EXCHANGE=0.  Not run with the ranks as threads of one process: eight
     streams share the process's four hardware queues, and a kernel waiting for a flag at the head of a queue would
     hold back the very kernel that raises it."""
     import torch

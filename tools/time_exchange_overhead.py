@@ -3,7 +3,8 @@ the ghost layer; every scatter packs / exchanges / unpacks the real halo volume,
 its own partner, through (a) the library's RCCL communicator, (b) the library's halo windows, (c) callbacks into
 torch.distributed, against (d) the same brick without any exchange.  The numerics are meaningless (ghosts receive the wrong owned values);
 the timings are not: host issue time per cycle, cycle time, i.e. what the exchange costs before any xGMI
-link is involved.   usage: python tools/time_exchange_overhead.py"""
+link is involved.   usage: python tools/time_exchange_overhead.py [n]   (n^3 owned cells, default 64; 32 = config 3's
+per-GPU share on eight GPUs)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -42,7 +43,8 @@ def self_layout(comm_factory):
 
 
 orig = problem.make_layout
-build = lambda: pm.PoissonHierarchy((64, 64, 128), (1, 2, 4), cheb_its=3, proc_dims=(1, 1, 2), rank=0, size=2)
+NC = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+build = lambda: pm.PoissonHierarchy((NC, NC, 2 * NC), (1, 2, 4), cheb_its=3, proc_dims=(1, 1, 2), rank=0, size=2)
 
 problem.make_layout = lambda lv, group=None, device="cuda", comm=None: pm.Layout(lv.size_local, lv.num_ghosts, device=device)
 H = build()
@@ -61,7 +63,10 @@ del H
 windows = pm.RcclComm(0, 1, pm.RcclComm.unique_id(), halo="windows")
 problem.make_layout = self_layout(lambda: windows)
 H = build()
-print("halo windows (direct stores + flags): %.3f ms per cycle (host issue time %.3f ms)" % cycle_ms(H))
+print("halo windows, as created (graph mode auto): %.3f ms per cycle (host issue time %.3f ms), %d replays"
+      % (*cycle_ms(H), H.mg.graph_replays()))
+H.mg.set_graph(False)
+print("halo windows (direct stores + flags), eager: %.3f ms per cycle (host issue time %.3f ms)" % cycle_ms(H))
 H.mg.set_graph(True)
 print("  the same through a hipGraph: %.3f ms per cycle (host issue time %.3f ms), %d replays"
       % (*cycle_ms(H), H.mg.graph_replays()))
