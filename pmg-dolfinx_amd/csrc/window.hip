@@ -102,6 +102,20 @@ __device__ inline bool wait_flag(const uint64_t* p, uint64_t target, long long l
   return true;
 }
 
+// Flags and the device-side sequence numbers are written with RELAXED stores behind ONE explicit release fence per block
+// (round 4, read at the ISA level: every release STORE is a buffer_wbl2 of its own, and the acquire-release count-in
+// adds a write-back and an invalidate -- five write-backs per put, three and an invalidate per get, 1.7 us each, in a
+// kernel that moves a few kilobytes).
+__device__ inline void store_sys_relaxed(uint64_t* p, uint64_t v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline void store_dev_relaxed(uint64_t* p, uint64_t v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr int WBATCH = 8; // entries a thread moves per pass: their loads are all issued before the first store
+
 // in[idx[i]] -> dst[slot][i], the entry's place in its neighbour's window (forward: the send list over the owned
 // entries; reverse: the receive list over the ghost entries, `in` already offset)
 __device__ __forceinline__ void window_put_body(const WindowDev* __restrict__ wp, int d, int n,
@@ -123,11 +137,24 @@ __device__ __forceinline__ void window_put_body(const WindowDev* __restrict__ wp
   __syncthreads();
   const uint64_t s = s_seq;
   double* const* to = dst + (long long)(s & 1) * n;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    *to[i] = in[idx[i]];
-  // (The count-in is an acquire-release read-modify-write at agent scope: the block that counts in last thereby
-  // acquires what the others released before their counts, so its flag stores are ordered after every block's data
-  // stores by the memory model and not only by issue order -- ADVICE r03; one fence per exchange.)
+  const int stride = gridDim.x * blockDim.x;
+  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += WBATCH * stride)
+  {
+    double v[WBATCH];
+    double* t[WBATCH];
+#pragma unroll
+    for (int k = 0; k < WBATCH; ++k)
+    {
+      const int i = i0 + k * stride;
+      const int ic = i < n ? i : n - 1;
+      t[k] = to[ic];
+      v[k] = in[idx[ic]];
+    }
+#pragma unroll
+    for (int k = 0; k < WBATCH; ++k)
+      if (i0 + k * stride < n)
+        *t[k] = v[k];
+  }
   // One release per block, by the thread that counts the block in (a fence per thread writes the L2 back a thousand
   // times per exchange: measured 48 us per exchange against 20).  The barrier alone does not order the OTHER waves'
   // stores before it -- at workgroup scope the compiler waits for LDS only -- so every wave first waits for the
@@ -137,20 +164,31 @@ __device__ __forceinline__ void window_put_body(const WindowDev* __restrict__ wp
   __shared__ int s_last;
   if (threadIdx.x == 0)
   {
-    release_sys();
-    const unsigned long long prev = __hip_atomic_fetch_add((unsigned long long*)&local[L_PACK_DONE + d], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = prev == (unsigned long long)gridDim.x - 1;
+    release_sys(); // this block's data: written back and acknowledged before anything below is issued
+    if (gridDim.x == 1)
+      s_last = 1;
+    else
+    {
+      // (acquire-release at agent scope: the block that counts in last thereby acquires what the others released
+      // before their counts, so its flag stores are ordered after every block's data by the memory model and not
+      // only by issue order -- ADVICE r03)
+      const unsigned long long prev = __hip_atomic_fetch_add((unsigned long long*)&local[L_PACK_DONE + d], 1ull,
+                                                             __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = prev == (unsigned long long)gridDim.x - 1;
+      if (s_last)
+        release_sys(); // cumulativity: what it acquired, released to the neighbours with the flags
+    }
   }
   __syncthreads();
   if (s_last && threadIdx.x < 64)
   {
-    release_sys(); // every block's stores (ordered before its count) before the flags
     if ((int)threadIdx.x < w.n)
-      store_sys(&w.nb_flags[threadIdx.x][F_ARRIVED + d * NBMAX + w.nb_slot[threadIdx.x]], s);
+      store_sys_relaxed(&w.nb_flags[threadIdx.x][F_ARRIVED + d * NBMAX + w.nb_slot[threadIdx.x]], s);
     if (threadIdx.x == 0)
     {
-      __hip_atomic_store(&local[L_PACK_DONE + d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&local[L_SENT + d], s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (gridDim.x > 1)
+        store_dev_relaxed(&local[L_PACK_DONE + d], 0ull);
+      store_dev_relaxed(&local[L_SENT + d], s); // read by the next kernel of this stream only
     }
   }
 }
@@ -163,6 +201,9 @@ __global__ void window_put_kernel(const WindowDev* __restrict__ wp, int d, int n
 }
 
 // my window -> out[idx[i]] (assign: ghosts; add: owned entries)
+// No fence at all on this side: the window is read with system-scope loads (served by memory), the values have come
+// back before the stores that use them are issued, and those stores are for the next kernel of this stream; the
+// "consumed" flag only tells the neighbour that the loads are done.
 template <bool ADD>
 __device__ __forceinline__ void window_get_body(const WindowDev* __restrict__ wp, int d, int n,
                                                 const int32_t* __restrict__ idx, const int32_t* __restrict__ pos,
@@ -180,34 +221,59 @@ __device__ __forceinline__ void window_get_body(const WindowDev* __restrict__ wp
     if (threadIdx.x == 0)
       s_seq = e;
   }
-  __syncthreads(); // nothing of the window is read before the first wave has seen the flags (acquire loads)
+  __syncthreads(); // nothing of the window is read before the first wave has seen the flags
   const uint64_t e = s_seq;
   const double* src = w.win + (long long)(e & 1) * w.stride + w.region[d];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+  const int stride = gridDim.x * blockDim.x;
+  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += WBATCH * stride)
   {
-    // system scope: the value a neighbour stored, not a line this XCD's L2 kept from two exchanges ago
-    const double v = __hip_atomic_load(&src[pos[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (ADD)
-      atomicAdd(&out[idx[i]], v);
-    else
-      out[idx[i]] = v;
+    double v[WBATCH];
+    int32_t o[WBATCH], ps[WBATCH];
+#pragma unroll
+    for (int k = 0; k < WBATCH; ++k)
+    {
+      const int i = i0 + k * stride;
+      const int ic = i < n ? i : n - 1;
+      o[k] = idx[ic];
+      ps[k] = pos[ic];
+    }
+#pragma unroll
+    for (int k = 0; k < WBATCH; ++k) // (all addresses first: the loads below are then issued back to back)
+      // system scope: the value a neighbour stored, not a line this XCD's L2 kept from two exchanges ago
+      v[k] = __hip_atomic_load(&src[ps[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+    for (int k = 0; k < WBATCH; ++k)
+      if (i0 + k * stride < n)
+      {
+        if (ADD)
+          atomicAdd(&out[o[k]], v[k]);
+        else
+          out[o[k]] = v[k];
+      }
   }
-  __syncthreads();
+  __syncthreads(); // every wave's loads have returned (their values were stored)
   __shared__ int s_last;
   if (threadIdx.x == 0)
   {
-    const unsigned long long prev = __hip_atomic_fetch_add((unsigned long long*)&local[L_UNPACK_DONE + d], 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = prev == (unsigned long long)gridDim.x - 1;
+    if (gridDim.x == 1)
+      s_last = 1;
+    else
+    {
+      const unsigned long long prev = __hip_atomic_fetch_add((unsigned long long*)&local[L_UNPACK_DONE + d], 1ull,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = prev == (unsigned long long)gridDim.x - 1;
+    }
   }
   __syncthreads();
   if (s_last && threadIdx.x < 64)
   {
     if ((int)threadIdx.x < w.n)
-      store_sys(&w.nb_flags[threadIdx.x][F_CONSUMED + d * NBMAX + w.nb_slot[threadIdx.x]], e);
+      store_sys_relaxed(&w.nb_flags[threadIdx.x][F_CONSUMED + d * NBMAX + w.nb_slot[threadIdx.x]], e);
     if (threadIdx.x == 0)
     {
-      __hip_atomic_store(&local[L_UNPACK_DONE + d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&local[L_GOT + d], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (gridDim.x > 1)
+        store_dev_relaxed(&local[L_UNPACK_DONE + d], 0ull);
+      store_dev_relaxed(&local[L_GOT + d], e);
     }
   }
 }
@@ -223,10 +289,12 @@ __global__ void window_get_kernel(const WindowDev* __restrict__ wp, int d, int n
 // The whole owner -> ghost exchange in ONE launch (round 4): every block puts its share, then waits for the
 // neighbours' data and unpacks its share.  For levels so small that a kernel is shorter than the gap between two
 // dependent launches (config 3's per-GPU share: 32^3 cells), where putting before and getting behind the interior
-// cells' launch hides nothing and costs a launch.  All blocks of the grid are resident together (put_blocks() <= 128),
+// cells' launch hides nothing and costs a launch.  All blocks of the grid are resident together (at most 64),
 // so a block that polls never keeps a block that still has to put from running -- on this rank; between ranks every
 // rank puts before it polls.
-__global__ void window_exchange_kernel(const WindowDev* __restrict__ wp, int n_send,
+constexpr int WHOLE_THREADS = 1024;
+__global__ void __launch_bounds__(WHOLE_THREADS)
+    window_exchange_kernel(const WindowDev* __restrict__ wp, int n_send,
                                        const int32_t* __restrict__ send_idx, double* const* __restrict__ dst,
                                        const double* __restrict__ in, int n_recv,
                                        const int32_t* __restrict__ recv_idx, const int32_t* __restrict__ recv_pos,
@@ -323,8 +391,10 @@ int window_exchange_whole(pmg_layout l, double* x, hipStream_t s)
   PMG_TRY(window_check(l));
   if (w->host.n == 0)
     return PMG_OK;
-  const int blocks = std::max(put_blocks(l->n_send), put_blocks(l->n_recv));
-  window_exchange_kernel<<<blocks, PUT_THREADS, 0, s>>>(w->dev, l->n_send, l->send_idx, w->fwd_dst, x, l->n_recv,
+  // one block (no count-in, one fence) up to 16 384 entries: the degree-1 and degree-2 levels of a 32^3 share
+  const long long n = std::max(l->n_send, l->n_recv);
+  const int blocks = (int)std::min<long long>(64, std::max<long long>(1, (n + 2 * WBATCH * WHOLE_THREADS - 1) / (2 * WBATCH * WHOLE_THREADS)));
+  window_exchange_kernel<<<blocks, WHOLE_THREADS, 0, s>>>(w->dev, l->n_send, l->send_idx, w->fwd_dst, x, l->n_recv,
                                                         l->recv_idx, w->recv_pos, x + l->size_local);
   PMG_HIP(hipGetLastError());
   return PMG_OK;
