@@ -1312,61 +1312,6 @@ int allreduce_max_small(pmg_layout l, int v, int* out, hipStream_t s)
   return PMG_OK;
 }
 
-// rows given by (global row, global column, value) on their owners -> the global matrix on every rank
-int gather_rows(pmg_layout l, int n_rows_global, const std::vector<int>& my_rows, const HostCsr& mine /* columns global */,
-                HostCsr& out, hipStream_t s)
-{
-  int wloc = 0;
-  for (int i = 0; i < mine.n; ++i)
-    wloc = std::max(wloc, mine.rp[i + 1] - mine.rp[i]);
-  int W = 1;
-  PMG_TRY(allreduce_max_small(l, wloc, &W, s));
-  W = std::max(W, 1);
-  const size_t ng = (size_t)n_rows_global;
-  std::vector<double> gc(ng * W, 0.0), gv(ng * W, 0.0);
-  for (int i = 0; i < mine.n; ++i)
-  {
-    const size_t g = (size_t)my_rows[i];
-    int k = 0;
-    for (int e = mine.rp[i]; e < mine.rp[i + 1]; ++e, ++k)
-    {
-      gc[g * W + k] = (double)(mine.ci[e] + 1); // column + 1: 0 = empty slot
-      gv[g * W + k] = mine.v[e];
-    }
-  }
-  PMG_TRY(host_allreduce_sum(l, gc.data(), gc.size(), s));
-  PMG_TRY(host_allreduce_sum(l, gv.data(), gv.size(), s));
-  out = HostCsr();
-  out.n = out.m = (int)ng;
-  out.rp.assign(ng + 1, 0);
-  const int nbk = ((int)ng + ROW_BLOCK - 1) / ROW_BLOCK;
-  std::vector<std::vector<int>> bci(nbk);
-  std::vector<std::vector<double>> bv(nbk);
-  std::atomic<long long> unowned(-1);
-  for_row_blocks((int)ng, [&](int blk, int r0, int r1, int) {
-    std::vector<std::pair<int, double>> row;
-    for (int g = r0; g < r1; ++g)
-    {
-      row.clear();
-      for (int k = 0; k < W; ++k)
-        if (gc[(size_t)g * W + k] > 0.5)
-          row.emplace_back((int)(gc[(size_t)g * W + k] - 0.5), gv[(size_t)g * W + k]);
-      if (row.empty())
-        unowned.store(g);
-      std::sort(row.begin(), row.end());
-      for (auto& e : row)
-      {
-        bci[blk].push_back(e.first);
-        bv[blk].push_back(e.second);
-      }
-      out.rp[g + 1] = (int)row.size();
-    }
-  });
-  PMG_REQUIRE(unowned.load() < 0, "pmg_amg: coarse row %lld is owned by no rank", unowned.load());
-  assemble_blocks(out, bci, bv);
-  return PMG_OK;
-}
-
 // largest eigenvalue of D^-1 A of the PARTITIONED operator by the power method on the device (the operator's own halo
 // exchange, the layout's reductions); the start vector depends on the global dof number only, so every partition of the
 // same problem iterates on the same vector
