@@ -571,9 +571,12 @@ constexpr bool unpaired_slice_reads(int P) { return (PMG_UNPAIRED_MASK >> P) & 1
 constexpr bool unpaired_slice_reads(int P) { return P == 5 || P == 8; }
 #endif
 
-// degrees whose kernel keeps the patch's dof list in LDS for the write-back (4 bytes per patch dof)
+// degrees whose kernel keeps the patch's dof list in LDS for the write-back (4 bytes per patch dof).  Round 4, two
+// rounds on one box against the list re-read from global memory: P = 5 454 against 460 - 470 us, P = 7 368 - 372 against
+// 376, P = 8 410 - 411 against 420; P = 4 +0.5 % (within noise, left out); P = 6 474 - 482 against 441 - 445 (the 9.6 KB
+// cost it a workgroup per CU).
 #ifndef PMG_LIST_LDS_MASK
-#define PMG_LIST_LDS_MASK 0
+#define PMG_LIST_LDS_MASK ((1 << 5) | (1 << 7) | (1 << 8))
 #endif
 constexpr bool list_in_lds(int P) { return (PMG_LIST_LDS_MASK >> P) & 1; }
 // degrees that run on the stream form of the kernel (stiffness_stream_kernel below); bit P of the mask
