@@ -184,6 +184,10 @@ def parse_args(argv=None):
                          "windows; the launcher's group is gloo).  Exercises the whole multi-rank path with real "
                          "inter-process exchanges; the line it prints says n_gpus = 1 and carries a `rehearsal` note -- "
                          "it is not a multi-GPU measurement")
+    ap.add_argument("--deadline", type=float, default=-1.0,
+                    help="seconds after which a run that has not finished prints a line with value null and what it was "
+                         "doing, and exits with code 5 (default: 1500 with several ranks -- a rank that died leaves "
+                         "the others waiting in a collective --, off on one rank; 0 = off)")
     ap.add_argument("--no-strong", action="store_true",
                     help="N > 1: skip the strong-scaled config-3 block AND with it the numeric gate against the C oracle "
                          "(the line then says parity 'unverified')")
@@ -296,6 +300,34 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # A run on several ranks that stops making progress (a rank died, a collective nobody else entered) still owes its
+    # caller ONE line: after --deadline seconds rank 0 prints what it has -- without a `value` -- and every rank exits.
+    watch = {"phase": "start-up", "out": None}
+    world_env, rank_env = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    deadline = args.deadline if args.deadline >= 0 else (1500.0 if world_env > 1 else 0.0)
+
+    def _expired():
+        msg = f"no result after {deadline:.0f} s; last phase: {watch['phase']}"
+        log(f"[rank {rank_env}] DEADLINE: {msg}")
+        if rank_env == 0:
+            line = dict(watch["out"] or {"metric": "DoFs/sec per p-MG V-cycle (Poisson, hex, p=4)", "unit": "DoF/s",
+                                         "n_gpus": world_env, "steps": args.steps, "warmup": args.warmup,
+                                         "higher_is_better": True, "dtype": "f64", "data": "synthetic"})
+            if line.get("value") is not None:
+                line["measured_before_the_run_stopped"] = {"value": line["value"], "ms_per_step": line.get("ms_per_step"),
+                                                           "note": "not gated against the oracle: not a result"}
+            line.update(value=None, ms_per_step=None, error=msg, incomplete=True)
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        else:
+            time.sleep(3.0)
+        os._exit(5)
+
+    if deadline > 0:
+        import threading
+
+        timer = threading.Timer(deadline, _expired)
+        timer.daemon = True
+        timer.start()
 
     import numpy as np
     import torch
@@ -359,6 +391,7 @@ def main():
         raise LaunchError(f"[rank {rank}] the communicator has {rccl_ranks} rank(s), --gpus is {args.gpus}")
 
     t0 = time.time()
+    watch["phase"] = "set-up of the weak-scaled hierarchy"
     H = pm.PoissonHierarchy(n_global, orders, kappa=2.0, cheb_its=args.cheb, proc_dims=dims, rank=rank, size=world,
                             comm=comm)
     torch.cuda.synchronize()
@@ -394,6 +427,7 @@ def main():
     # ---- warm-up, then EXACTLY K timed V-cycles (stationary iteration, examples/pmg/main.cpp:362-367) ----
     # `value` is the EAGER cycle (stream-ordered launches) on every route; the replayed cycle is reported next to it
     H.mg.set_graph(False)
+    watch["phase"] = "warm-up and timed cycles of the headline"
     for _ in range(args.warmup):
         H.mg.apply(b, x)
     sync_all()
@@ -551,6 +585,8 @@ def main():
         },
         "roofline": roofline,
     }
+    watch["out"] = out
+    watch["phase"] = "after the headline"
     if args.share_gpu:
         out["rehearsal"] = (f"{world} ranks SHARE ONE GPU (--share-gpu): a rehearsal of the multi-rank path with real "
                             "inter-process exchanges, not a multi-GPU measurement; `value` is the aggregate of the "
@@ -603,6 +639,7 @@ def main():
                 continue
             entry = {"communicator": "RCCL" if ckind == "rccl" else "windows (direct stores, no transport library)",
                      "halo": halo, "captured": captured}
+            watch["phase"] = f"strong-scaling route {name}"
             try:
                 if ckind == args.comm and halo == (args.halo if ckind == "rccl" else "windows") and comm is not None:
                     rcomm = comm  # the communicator of the headline
@@ -732,6 +769,7 @@ def main():
 
     if multi and args.scaling == "weak" and not args.no_strong:
         _strong_block()
+        watch["phase"] = "after the strong-scaling block"
     elif multi:
         out["parity"] = {"gate": "unverified: the strong-scaling block and its gate against the C oracle were skipped "
                                  "(--no-strong or --scaling strong)"}
@@ -1055,6 +1093,8 @@ def main():
         log("PARITY FAILURE: " + f)
     finish_line(out, parity_failures)
 
+    if deadline > 0:
+        timer.cancel()
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)

@@ -186,3 +186,20 @@ def test_oracle_cycle_bytes_counts_the_applications_the_oracle_runs():
     only_applies = b.oracle_cycle_bytes(orders, ncells, [0, 0, 0], k)
     maps = sum(2 * 4.0 * ((p + 1) ** 3 + (q + 1) ** 3) * ncells for p, q in ((2, 1), (4, 2)))
     assert abs(only_applies - maps - ncells * (7 * cell(4) + 6 * cell(2) + 2 * cell(1))) < 1.0
+
+
+def test_a_run_that_stops_still_prints_its_line():
+    """--deadline: a run that has not finished in time (on several ranks: a rank died and the others wait in a
+    collective) prints ONE line without a `value`, naming the phase it was in, and exits with code 5.  Here the
+    deadline falls into the start-up of a one-rank run (importing torch takes longer than 50 ms)."""
+    import json
+
+    r = subprocess.run([sys.executable, BENCH, "--deadline", "0.05", "--steps", "1", "--warmup", "0"], env=_env(),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 5, (r.returncode, r.stderr[-400:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["incomplete"] is True
+    assert "no result after" in line["error"] and "start-up" in line["error"]
+    assert line["metric"].startswith("DoFs/sec") and line["n_gpus"] == 1
