@@ -633,6 +633,8 @@ def main():
                "scaling": "strong", "unit": "DoF/s", "routes": {}}
         oracle = {}
         value_route = None
+        headline_route = None  # the route that runs on the headline's own communicator, eagerly, as `value` was timed
+        route_failures = {}
         for name, ckind, halo, captured, skip in strong_routes(world, args.share_gpu, args.comm):
             if skip:
                 res["routes"][name] = {"skipped": skip}
@@ -656,6 +658,8 @@ def main():
             if int(okc.item()) == 0:
                 res["routes"][name] = {**entry, "skipped": "communicator could not be created on every rank"}
                 continue
+            if rcomm is comm and (headline_route is None or (not captured and res["routes"][headline_route]["captured"])):
+                headline_route = name  # (the eager route on that communicator if there is one, else the captured one)
 
             def hook(lv):
                 if args.corrupt_halo and rank == world - 1 and lv.P == P and len(lv.recv_indices) >= 8:
@@ -734,8 +738,8 @@ def main():
                     value_route = name
             else:
                 entry.update(value=None, parity_failed=True)
-                parity_failures.append(f"strong-scaling route {name}: the {world}-rank cycle does not reproduce the "
-                                       f"single-domain C oracle ({entry.get('gate')})")
+                route_failures[name] = (f"strong-scaling route {name}: the {world}-rank cycle does not reproduce the "
+                                        f"single-domain C oracle ({entry.get('gate')})")
             Hs.mg.set_graph(None)
             res["routes"][name] = entry
             res.update(fine_dofs_global=nd_s, local_dofs=[lv.size_local for lv in Hs.levels],
@@ -749,8 +753,19 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
         if rank == 0:
+            # The headline ran on ONE transport.  It is void if that transport's route fails the gate, if no route
+            # passes, or if no route ran on its communicator at all; another route that fails loses its own numbers and
+            # is named in the line (`parity.routes_failed`), loudly, without taking a validated headline with it.
             if value_route is None:
                 parity_failures.append("strong-scaling gate: no route reproduced the C oracle")
+                parity_failures.extend(route_failures.values())
+            elif headline_route is None or headline_route in route_failures:
+                parity_failures.extend(route_failures.values())
+                if headline_route is None:
+                    parity_failures.append("strong-scaling gate: no route ran on the headline's communicator")
+            for msg in route_failures.values():
+                log("GATE FAILURE: " + msg)
+            if value_route is None:
                 res.update(value=None, ms_per_step=None, value_route=None)
             else:
                 vr = res["routes"][value_route]
@@ -760,7 +775,9 @@ def main():
                                      f"C oracle on the {args.n}^3 problem (iterate {GATE_TOLERANCE:g}, residual norms "
                                      f"{GATE_RNORM_TOLERANCE:g}); the weak-scaled `value` runs the same kernels and "
                                      f"the same exchange on {world} such bricks",
-                             "routes_passed": [k for k, v in res["routes"].items() if v.get("gate", {}).get("passed")]}
+                             "routes_passed": [k for k, v in res["routes"].items() if v.get("gate", {}).get("passed")],
+                             "routes_failed": sorted(route_failures),
+                             "headline_route": headline_route}
         # all ranks agree on failure (rank 0 decides)
         nf = torch.tensor([len(parity_failures) if rank == 0 else 0], device=ctl)
         dist.broadcast(nf, src=0)
