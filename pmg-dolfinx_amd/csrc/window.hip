@@ -114,6 +114,17 @@ __device__ inline void store_dev_relaxed(uint64_t* p, uint64_t v)
 {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+#ifdef PMG_STAMPS // diagnostic build: readings of the 100 MHz clock by thread 0 of block 0 of the last window kernel
+__device__ unsigned long long g_wstamp[16];
+#define WSTAMP(i)                                                                                                     \
+  do                                                                                                                  \
+  {                                                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x == 0)                                                                          \
+      g_wstamp[i] = __builtin_amdgcn_s_memrealtime();                                                                 \
+  } while (0)
+#else
+#define WSTAMP(i)
+#endif
 constexpr int WBATCH = 8; // entries a thread moves per pass: their loads are all issued before the first store
 
 // in[idx[i]] -> dst[slot][i], the entry's place in its neighbour's window (forward: the send list over the owned
@@ -135,6 +146,7 @@ __device__ __forceinline__ void window_put_body(const WindowDev* __restrict__ wp
       s_seq = s;
   }
   __syncthreads();
+  WSTAMP(1); // sequence number read, slot free
   const uint64_t s = s_seq;
   double* const* to = dst + (long long)(s & 1) * n;
   const int stride = gridDim.x * blockDim.x;
@@ -159,12 +171,15 @@ __device__ __forceinline__ void window_put_body(const WindowDev* __restrict__ wp
   // times per exchange: measured 48 us per exchange against 20).  The barrier alone does not order the OTHER waves'
   // stores before it -- at workgroup scope the compiler waits for LDS only -- so every wave first waits for the
   // acknowledgement of its own stores.
+  WSTAMP(2); // stores issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  WSTAMP(3); // stores acknowledged, all waves
   __shared__ int s_last;
   if (threadIdx.x == 0)
   {
     release_sys(); // this block's data: written back and acknowledged before anything below is issued
+    WSTAMP(4); // release fence done
     if (gridDim.x == 1)
       s_last = 1;
     else
@@ -191,6 +206,7 @@ __device__ __forceinline__ void window_put_body(const WindowDev* __restrict__ wp
       store_dev_relaxed(&local[L_SENT + d], s); // read by the next kernel of this stream only
     }
   }
+  WSTAMP(5); // flags stored
 }
 
 __global__ void window_put_kernel(const WindowDev* __restrict__ wp, int d, int n,
@@ -222,6 +238,7 @@ __device__ __forceinline__ void window_get_body(const WindowDev* __restrict__ wp
       s_seq = e;
   }
   __syncthreads(); // nothing of the window is read before the first wave has seen the flags
+  WSTAMP(6); // arrival seen
   const uint64_t e = s_seq;
   const double* src = w.win + (long long)(e & 1) * w.stride + w.region[d];
   const int stride = gridDim.x * blockDim.x;
@@ -252,6 +269,7 @@ __device__ __forceinline__ void window_get_body(const WindowDev* __restrict__ wp
       }
   }
   __syncthreads(); // every wave's loads have returned (their values were stored)
+  WSTAMP(7); // unpacked
   __shared__ int s_last;
   if (threadIdx.x == 0)
   {
@@ -300,10 +318,18 @@ __global__ void __launch_bounds__(WHOLE_THREADS)
                                        const int32_t* __restrict__ recv_idx, const int32_t* __restrict__ recv_pos,
                                        double* __restrict__ ghosts)
 {
+  WSTAMP(0); // entry
   window_put_body(wp, 0, n_send, send_idx, dst, in);
   __syncthreads();
   window_get_body<false>(wp, 0, n_recv, recv_idx, recv_pos, ghosts);
+  WSTAMP(8); // end
 }
+#ifdef PMG_STAMPS
+extern "C" int pmg_debug_read_window_stamps(unsigned long long* out)
+{
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamp), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 constexpr size_t ALIGN = 32; // doubles: every neighbour's segment starts on a 256-byte boundary
 
@@ -324,8 +350,12 @@ size_t segment_offsets(const int32_t* counts, int n, std::vector<size_t>& off)
 constexpr int PUT_THREADS = 256;
 int put_blocks(int n)
 {
-  long long b = ((long long)n + 8 * PUT_THREADS - 1) / (8 * PUT_THREADS);
-  return (int)(b < 1 ? 1 : (b > 128 ? 128 : b));
+  static const int per_thread = [] { // tuning: PMG_WINDOW_ENTRIES_PER_THREAD
+    const char* e = std::getenv("PMG_WINDOW_ENTRIES_PER_THREAD");
+    return e ? std::max(1, std::atoi(e)) : 8;
+  }();
+  long long b = ((long long)n + per_thread * PUT_THREADS - 1) / (per_thread * PUT_THREADS);
+  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
 }
 } // namespace
 
@@ -391,9 +421,19 @@ int window_exchange_whole(pmg_layout l, double* x, hipStream_t s)
   PMG_TRY(window_check(l));
   if (w->host.n == 0)
     return PMG_OK;
-  // one block (no count-in, one fence) up to 16 384 entries: the degree-1 and degree-2 levels of a 32^3 share
   const long long n = std::max(l->n_send, l->n_recv);
-  const int blocks = (int)std::min<long long>(64, std::max<long long>(1, (n + 2 * WBATCH * WHOLE_THREADS - 1) / (2 * WBATCH * WHOLE_THREADS)));
+  // Entries per block of 1 024 threads (tuning: PMG_WINDOW_ENTRIES_PER_BLOCK).  In-kernel clock readings
+  // (-DPMG_STAMPS, tools/stamp_exchange.py) show where the kernel's time is: not in its fences (0.4 us) or flags
+  // (0.4 - 1 us each way) but in the passes of its two copy loops, 1.6 - 3.3 us each (list -> gather -> store, all
+  // dependent).  One pass of four entries per thread, paid for with a count-in once there are several blocks:
+  // 16 384 / 8 192 / 4 096 / 2 048 entries per block = 13.5 / 11.3 / 9.7 / 9.6 us for the 12 675 entries of a degree-2
+  // level, 18.6 / 12.2 / 10.6 / 10.9 us for the 83 205 of a degree-4 level, 1.018 / 0.965 / 0.948 / 0.944 ms per cycle
+  // of a 32^3 share.
+  static const int per_block = [] {
+    const char* e = std::getenv("PMG_WINDOW_ENTRIES_PER_BLOCK");
+    return e ? std::max(256, std::atoi(e)) : 4096;
+  }();
+  const int blocks = (int)std::min<long long>(64, std::max<long long>(1, (n + per_block - 1) / per_block));
   window_exchange_kernel<<<blocks, WHOLE_THREADS, 0, s>>>(w->dev, l->n_send, l->send_idx, w->fwd_dst, x, l->n_recv,
                                                         l->recv_idx, w->recv_pos, x + l->size_local);
   PMG_HIP(hipGetLastError());
