@@ -361,6 +361,18 @@ long long pmg_laplacian_geometry_bytes(pmg_laplacian op);
  * pmg_laplacian_apply_streams returns 1 or 2. */
 int pmg_laplacian_launches_per_apply(pmg_laplacian op);
 int pmg_laplacian_apply_streams(pmg_laplacian op);
+/* Chain form of the interior launches (degree 4; csrc/patches.hpp ChainPlan, stiffness_chain_kernel): the interior
+ * patches of a large level strung together along the axis with the fewest patch positions, one persistent workgroup
+ * of sixteen wavefronts per chain; the gather of the next patch and the write-back of the previous one run under the
+ * cell loop of the patch in hand, dofs shared by consecutive patches stay in LDS, a chain colour is one launch (four
+ * on a box instead of eight patch colours).  Same sums as the patch launches to rounding.  Built when the operator is
+ * created if PMG_CHAIN=1 (where every colour's chains fill the GPU) or =2 (whenever the patches form a tensor grid;
+ * tests); PMG_CHAIN=0 never.  _chain_available: 1 if the operator has chains; _chain_form: 1 if they are in use;
+ * _set_chain_form switches (PMG_ERR_INVALID when there are none).  The boundary cell list, merged small levels,
+ * the affine mode and batched geometry keep the patch launches. */
+int pmg_laplacian_chain_available(pmg_laplacian op);
+int pmg_laplacian_chain_form(pmg_laplacian op);
+int pmg_laplacian_set_chain_form(pmg_laplacian op, int on);
 int pmg_set_merge_threshold(long long patch_dofs);
 /* Dominant-kernel timing hook for bench.py: enqueue `reps` times every
  * stiffness-kernel launch of one operator application (no halo, no zero-fill)

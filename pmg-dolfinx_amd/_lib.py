@@ -107,6 +107,9 @@ _SIGS = {
     "pmg_laplacian_set_geometry_mode": (C.c_int, [vp, C.c_int]),
     "pmg_laplacian_launches_per_apply": (C.c_int, [vp]),
     "pmg_laplacian_apply_streams": (C.c_int, [vp]),
+    "pmg_laplacian_chain_available": (C.c_int, [vp]),
+    "pmg_laplacian_chain_form": (C.c_int, [vp]),
+    "pmg_laplacian_set_chain_form": (C.c_int, [vp, C.c_int]),
     "pmg_set_merge_threshold": (C.c_int, [C.c_longlong]),
     "pmg_laplacian_set_profiling": (C.c_int, [vp, C.c_int]),
     "pmg_laplacian_read_profile": (C.c_int, [vp, c_dp, C.POINTER(C.c_longlong)]),
@@ -175,6 +178,7 @@ _SIGS = {
 # functions whose int return value is a count, not a status
 _COUNT_FUNCS = {"pmg_multigrid_graph_replays", "pmg_amg_num_levels", "pmg_laplacian_geometry_bytes", "pmg_comm_rank", "pmg_comm_size", "pmg_comm_capture_overlaps", "pmg_cg_coefficients", "pmg_cg_compute_eigenvalues", "pmg_multigrid_apply_counts", "pmg_version",
                 "pmg_laplacian_degree", "pmg_laplacian_launches_per_apply", "pmg_laplacian_apply_streams", "pmg_laplacian_is_affine",
+                "pmg_laplacian_chain_available", "pmg_laplacian_chain_form",
                 "pmg_laplacian_node_order", "pmg_layout_forward_scatters"}
 
 _lib = None

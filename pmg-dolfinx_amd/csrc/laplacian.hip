@@ -90,6 +90,13 @@ struct pmg_laplacian_s
   int n_launch_l = 0;
   int n_plain = 0;
   bool needs_zero = false; // some local dof belongs to no listed cell
+  // chain form of the interior launches (patches.hpp ChainPlan, stiffness_chain_kernel): available / in use
+  bool chain_ok = false, chain_on = false;
+  uint32_t* cdofs = nullptr;
+  uint32_t* ccar = nullptr;
+  int32_t* chain_off = nullptr;
+  int32_t* chain_patch = nullptr;
+  std::vector<int32_t> chain_first, chain_count; // chains of each colour
   bool stream_policy = true; // the stored tensor exceeds the Infinity Cache: nt loads / stores (launch_stiffness)
   double* diag_inv = nullptr; // [size_local + num_ghosts]
   bool have_diag = false;
@@ -1489,6 +1496,351 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   }
 }
 
+// ---- the hot kernel, chain form (round 4) ------------------------------------------------------
+//
+// One PERSISTENT workgroup of sixteen wavefronts per chain of patches (patches.hpp, ChainPlan), one wavefront per item
+// of the patch in hand.  What the column kernel does one phase after the other -- list -> gather -> cells -> list ->
+// store, eight launches of two generations of workgroups -- overlaps here:
+//   * while the wavefronts are in the cell loop of patch c, the dof list of patch c + 1 lands in LDS (LDS-direct
+//     loads: no registers, nobody waits);
+//   * leaving the cell loop a wavefront requests its share of patch c + 1's x and y values; they are in flight
+//     during the closing barrier and the write-back of patch c and are put into the SECOND pair of patch arrays;
+//   * the tensor is one stream per wavefront across the patches of the chain (the refill behind the last two layers
+//     of an item requests the first two layers of the wavefront's item in the NEXT patch), so it keeps flowing
+//     through both barriers;
+//   * dofs shared by consecutive patches of the chain go from one accumulator to the next inside LDS.
+// The LDS-direct loads.  Told about them (the builtin), the compiler drains the memory counter before the next LDS
+// read of ANY array (measured in the ISA: `s_waitcnt vmcnt(0)` at the top of the cell loop); issued with inline
+// assembly it does not see them, and since the counter retires in order every wait it places for a load of its own
+// that is YOUNGER than them... is unaffected, for an OLDER one becomes a wait for them as well.  So they sit where no
+// such wait follows: behind the layer loop (the last wait for the tensor lies before it), in front of the gather's
+// loads, whose waits they precede anyway -- and they fetch the lists of the patch TWO ahead, which nobody reads before
+// the iteration after this one (three list buffers, two buffers of carry words and cell ids).
+__device__ __forceinline__ void lds_dma4s(const void* sbase, unsigned voff, unsigned lds_byte)
+{
+  // every lane: 4 bytes from sbase + voff to LDS[lds_byte + 4 * lane]
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_byte)
+               : "memory");
+}
+
+template <int P>
+struct ChainShape
+{
+  using Sh = Shape<P>;
+  static constexpr int NW = 16, THREADS = NW * 64;
+  static constexpr int ITER = (Sh::MAXM + THREADS - 1) / THREADS;
+  static constexpr int LCAP = (Sh::MAXM + 63) / 64 * 64; // list entries the LDS-direct loads write (whole wavefronts)
+  static constexpr bool OK = Sh::WPC == 1 && !gflat(Sh::ND) && !gdense(Sh::ND) && !gring(Sh::ND) && Sh::ITEMS <= NW
+                             && Sh::ND >= 2 && Sh::K <= 64;
+};
+constexpr bool chain_form(int P) { return P == 4; } // degrees the chain kernel is built for
+#ifndef PMG_CHAIN_DEFAULT
+#define PMG_CHAIN_DEFAULT 0 // the mode when PMG_CHAIN is not set (pmg_laplacian_create_ordered)
+#endif
+
+template <int P, bool NT>
+__global__ void __launch_bounds__(ChainShape<P>::THREADS)
+    stiffness_chain_kernel(const double* __restrict__ x, double* __restrict__ y, const double2* __restrict__ G,
+                           const int32_t* __restrict__ poff, const uint32_t* __restrict__ cdofs,
+                           const uint32_t* __restrict__ ccar, const int32_t* __restrict__ lmap_id,
+                           const uint16_t* __restrict__ lmaps, const int32_t* __restrict__ pcell,
+                           const int32_t* __restrict__ pncell, const double* __restrict__ kappa,
+                           const double* __restrict__ Dg, const int32_t* __restrict__ chain_off,
+                           const int32_t* __restrict__ chain_patch, int first_chain)
+{
+  using Sh = Shape<P>;
+  using Ch = ChainShape<P>;
+  constexpr int ND = Sh::ND, N = Sh::N, K = Sh::K, NQ2 = Sh::NQ2, CW = Sh::CW;
+  constexpr int MAXM = Sh::MAXM, THREADS = Ch::THREADS, ITER = Ch::ITER, LCAP = Ch::LCAP, NW = Ch::NW;
+  constexpr int WL = CW * NQ2;
+  constexpr int GPS = NQ2, GLS = 3 * GPS;
+  constexpr bool UNPAIRED = unpaired_slice_reads(P);
+  static_assert(Ch::OK, "chain kernel: one wavefront per item, default G layout, at most sixteen items per patch");
+  __shared__ double sD[ND * ND];
+  __shared__ double skap[2 * K + 1]; // (+ 1: the spare element the lanes without an entry write)
+  __shared__ double sx[2 * MAXM + 1];
+  __shared__ double sy[2 * MAXM + 1];
+  __shared__ double ssl[NW * 3 * WL];
+  __shared__ uint32_t sm[3 * LCAP];   // dof lists of the patch in hand, the next one and the one after
+  __shared__ uint32_t scar[2 * LCAP]; // carry positions / read-y flags of the next patch and the one after
+  __shared__ uint32_t spc[2 * 64];    // cell ids, likewise
+
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const bool lane_ok = lane < WL;
+  const int lw = lane_ok ? lane : WL - 1;
+  const int cw = lw / NQ2;
+  const int ab = lw - cw * NQ2;
+  const int a = ab / ND, b = ab - a * ND;
+  const int slot = wave * CW + cw;
+  const int slotc = slot < K ? slot : K - 1;
+  const int ch = first_chain + blockIdx.x;
+  const int c0 = chain_off[ch], nck = chain_off[ch + 1] - c0;
+#ifdef PMG_CHAIN_PRIO // experiment: issue priority against the age order of the wavefronts on a SIMD
+  switch (PMG_CHAIN_PRIO == 1 ? wave >> 2 : 3 - (wave >> 2))
+  {
+  case 1: __builtin_amdgcn_s_setprio(1); break;
+  case 2: __builtin_amdgcn_s_setprio(2); break;
+  case 3: __builtin_amdgcn_s_setprio(3); break;
+  default: break;
+  }
+#endif
+  PMG_STAMP_DECL; // (diagnostic build: the phases of the chain's middle patch, tools/stamp_chain.py)
+  PMG_STAMP(0);   // entry
+#ifdef PMG_STAMPS
+#define PMG_CSTAMP(i)                                                                                                 \
+  if (c == nck / 2)                                                                                                   \
+  PMG_STAMP(i)
+#else
+#define PMG_CSTAMP(i)
+#endif
+
+  // element (layer 0, pair 0) of this lane's column in patch p, as a 32-bit offset from G
+  auto gitem = [&](int p) -> unsigned { return (unsigned)p * (unsigned)(K * 3 * N) + (unsigned)(slotc * 3 * N + ab); };
+  double2 gq[2][3];
+  auto gfetch = [&](int s, unsigned base, int layer) {
+    gq[s][0] = gload<NT>(G + (base + (unsigned)(layer * GLS)));
+    gq[s][1] = gload<NT>(G + (base + (unsigned)(layer * GLS + GPS)));
+    gq[s][2] = gload<NT>(G + (base + (unsigned)(layer * GLS + 2 * GPS)));
+  };
+  const unsigned sm0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)&sm[wave * 64]);
+  const unsigned scar0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)&scar[wave * 64]);
+  const unsigned spc0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)&spc[0]);
+  // the lists of the chain's patch number cc into the buffers it owns (entries past the list's end repeat the last one)
+  auto dma_lists = [&](int cc) {
+    const int pn = chain_patch[c0 + (cc < nck ? cc : nck - 1)];
+    const int offn = poff[pn], Mn = poff[pn + 1] - offn;
+    const int b3 = cc % 3, b2 = cc & 1;
+#pragma unroll
+    for (int k = 0; k < ITER; ++k)
+    {
+      if (k * THREADS + wave * 64 < LCAP) // (wave-uniform)
+      {
+        const int i = t + k * THREADS;
+        const unsigned vo = 4u * (unsigned)(i < Mn ? i : Mn - 1);
+        lds_dma4s(cdofs + offn, vo, sm0 + 4u * (unsigned)(b3 * LCAP + k * THREADS));
+        lds_dma4s(ccar + offn, vo, scar0 + 4u * (unsigned)(b2 * LCAP + k * THREADS));
+      }
+    }
+    if (wave == 0)
+    {
+      // (the lane number made opaque: hoisted out of the loop, this offset is held -- in the event, spilled -- through
+      // the cell loop, and its reload drains the memory counter)
+      int lo = lane;
+      asm volatile("" : "+v"(lo));
+      lds_dma4s(pcell + (size_t)pn * K, 4u * (unsigned)(lo < K ? lo : K - 1), spc0 + 256u * (unsigned)b2);
+    }
+  };
+  // What a thread holds of the next patch between the cell loop and barrier #2 lives in the loop body's scope: nothing
+  // of it is carried around the loop (a value defined under one condition and used under another is a loop-carried
+  // register as far as the allocator is concerned, live through the cell loop: spilled).  For the same reason the
+  // next-patch steps are UNCONDITIONAL: behind its last patch a chain gathers that patch once more into the free
+  // buffers (reads only; nobody uses them).
+#define PMG_CHAIN_GATHER(pn_, b3_, b2_)                                                                                \
+  uint32_t m[ITER], cf[ITER];                                                                                         \
+  double xv[ITER], yv[ITER], kapn;                                                                                    \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < ITER; ++k)                                                                  \
+    {                                                                                                                 \
+      /* (a thread past the end of the buffer re-reads its OWN first entry: an entry another wavefront fetched  */     \
+      /* may not have landed yet, and what is there instead is no dof number) */                                      \
+      const int i = t + k * THREADS < LCAP ? t + k * THREADS : t;                                                     \
+      m[k] = sm[(b3_) * LCAP + i];                                                                                    \
+      cf[k] = scar[(b2_) * LCAP + i];                                                                                 \
+    }                                                                                                                 \
+    /* (wave 0 put the cell ids there, and only its lanes use them) */                                                \
+    int lo_ = lane;                                                                                                   \
+    asm volatile("" : "+v"(lo_));                                                                                     \
+    const int cellk = wave == 0 ? (int)spc[(b2_) * 64 + (lo_ < K ? lo_ : K - 1)] : 0;                                 \
+    _Pragma("unroll") for (int k = 0; k < ITER; ++k)                                                                  \
+    {                                                                                                                 \
+      const uint32_t dof = m[k] & CD_MASK;                                                                            \
+      xv[k] = x[dof];                                                                                                 \
+      const double* ya = (cf[k] & CC_ACC) ? (const double*)(y + dof) : (x + dof);                                     \
+      yv[k] = *ya;                                                                                                    \
+    }                                                                                                                 \
+    /* (the column's offset in the position table from the opaque lane number: a scalar base + a 32-bit offset, */   \
+    /* nothing of it held through the cell loop) */                                                                   \
+    const int lw_ = lo_ < WL ? lo_ : WL - 1, cw_ = lw_ / NQ2, sl_ = wave * CW + cw_;                                  \
+    const unsigned lmo = (unsigned)((sl_ < K ? sl_ : K - 1) * N + (lw_ - cw_ * NQ2));                                 \
+    const uint16_t* lm = lmaps + (size_t)lmap_id[pn_] * (K * N);                                                      \
+    _Pragma("unroll") for (int k = 0; k < ND; ++k) ln[k] = lm[lmo + (unsigned)(k * NQ2)];                             \
+    kapn = kappa[cellk >= 0 ? cellk : 0];                                                                             \
+  }
+  // (no branch: a load whose only use sits under a condition is SUNK into it -- behind the barrier, with a full wait
+  // in front of its use; the lanes past the end of the list write a spare element instead)
+#define PMG_CHAIN_INIT(buf_, Mn_)                                                                                      \
+  {                                                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < ITER; ++k)                                                                  \
+    {                                                                                                                 \
+      const int i = t + k * THREADS;                                                                                  \
+      const int at = i < (Mn_) ? (buf_) * MAXM + i : 2 * MAXM;                                                        \
+      sx[at] = (m[k] & CD_BC) ? 0.0 : xv[k]; /* src/laplacian.hpp:186-189 */                                          \
+      const unsigned cpos = cf[k] & 0xffffu;                                                                          \
+      /* the sum the previous patch of the chain left for this dof */                                                 \
+      const double carry = sy[((buf_) ^ 1) * MAXM + (cpos != CC_NONE ? cpos : 0u)];                                   \
+      sy[at] = ((cf[k] & CC_ACC) ? yv[k] : 0.0) + (cpos != CC_NONE ? carry : 0.0);                                    \
+    }                                                                                                                 \
+    skap[t < K ? (buf_) * K + t : 2 * K] = kapn;                                                                      \
+    /* the column's positions as indices into the double-buffered patch arrays: consumed HERE, in front of the      */ \
+    /* write-back -- left for the top of the next cell loop, their wait is one for the stores issued in between     */ \
+    _Pragma("unroll") for (int k = 0; k < ND; ++k) ln[k] += (buf_) * MAXM;                                            \
+  }
+
+  // ---- prologue: the first patch of the chain, gathered as every later one will be
+  int ln[ND]; // the positions of this lane's column in the list of the patch the next cell loop works on
+  int p = chain_patch[c0];
+  int M = poff[p + 1] - poff[p];
+  {
+    dma_lists(0);
+    wait_vmcnt<0>();
+    dma_lists(1);
+    const double dval = Dg[t < ND * ND ? t : ND * ND - 1];
+    PMG_CHAIN_GATHER(p, 0, 0)
+    {
+      const unsigned g0 = gitem(p);
+      gfetch(0, g0, 0);
+      gfetch(1, g0, 1);
+    }
+    if (t < ND * ND)
+      sD[t] = dval;
+    PMG_CHAIN_INIT(0, M) // (no carry in a chain's first patch)
+  }
+  lds_barrier();
+
+  double Da[ND], Db[ND], DTa[ND], DTb[ND]; // D[a][.], D[b][.], D[.][a], D[.][b]
+#pragma unroll
+  for (int mm = 0; mm < ND; ++mm)
+  {
+    Da[mm] = sD[a * ND + mm];
+    Db[mm] = sD[b * ND + mm];
+    DTa[mm] = sD[mm * ND + a];
+    DTb[mm] = sD[mm * ND + b];
+  }
+  double* q_s = ssl + wave * (3 * WL) + cw * NQ2;
+  double* gr_s = q_s + WL;
+  double* gs_s = q_s + 2 * WL;
+
+  for (int c = 0; c < nck; ++c)
+  {
+    const int cur = c & 1, nxt = cur ^ 1;
+    const int pn = c + 1 < nck ? chain_patch[c0 + c + 1] : p;
+    const int Mn = poff[pn + 1] - poff[pn];
+    const int nc = pncell[p];
+    const unsigned gthis = gitem(p), gnext = gitem(pn);
+    PMG_CSTAMP(1); // top of the patch
+    // Every wavefront runs the cell loop, also one whose item lies beyond the patch's cells (a short patch at the edge
+    // of the cell list: clamped slot, exact zeros added): a branch around the loop makes the tensor registers values
+    // that meet at a join, and the copies there wait for the loads in flight -- the stream would stop at every patch.
+    {
+      int l[ND];
+#pragma unroll
+      for (int k = 0; k < ND; ++k)
+        l[k] = ln[k];
+      const double kap = skap[cur * K + slotc];
+      double u[ND], Aq[ND];
+#pragma unroll
+      for (int k = 0; k < ND; ++k)
+      {
+        u[k] = kap * sx[l[k]];
+        Aq[k] = 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < ND; ++k)
+      {
+        const int s = k & 1;
+        q_s[ab] = u[k];
+        wave_fence();
+        double qr = 0.0, qs = 0.0, qt = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < ND; ++mm)
+        {
+          qr += Da[mm] * slice_load<UNPAIRED>(q_s[mm * ND + b]); // d/dx: sum over a, :195-199
+          qs += Db[mm] * slice_load<UNPAIRED>(q_s[a * ND + mm]); // d/dy: sum over b, :206-210
+          qt += Dg[k * ND + mm] * u[mm];                         // d/dz: registers, uniform table, :214-218
+        }
+        const double2 g01 = gq[s][0], g23 = gq[s][1], g45 = gq[s][2];
+        const double fr = g01.x * qr + g01.y * qs + g23.x * qt; // :233 (kappa: in u, above)
+        const double fs = g01.y * qr + g23.y * qs + g45.x * qt; // :234
+        const double ft = g23.x * qr + g45.x * qs + g45.y * qt; // :235
+        if (k + 2 < ND)
+          gfetch(s, gthis, k + 2);
+        else
+          gfetch(s, gnext, s); // the head of the wavefront's item in the next patch, into the slot it belongs in
+        gr_s[ab] = fr;
+        gs_s[ab] = fs;
+        wave_fence();
+        double acc = 0.0;
+#pragma unroll
+        for (int mm = 0; mm < ND; ++mm)
+        {
+          acc += DTa[mm] * slice_load<UNPAIRED>(gr_s[mm * ND + b]); // :246-251
+          acc += DTb[mm] * slice_load<UNPAIRED>(gs_s[a * ND + mm]); // :255-259
+          Aq[mm] += Dg[k * ND + mm] * ft;                           // :263-267
+        }
+        Aq[k] += acc;
+        wave_fence();
+      }
+      const bool contributes = lane_ok && slot < nc; // lanes without a cell add an exact zero
+#pragma unroll
+      for (int k = 0; k < ND; ++k)
+        atomicAdd(&sy[l[k]], contributes ? Aq[k] : 0.0); // :270,277 -- in LDS (ds_add_f64)
+    }
+    PMG_CSTAMP(2); // cell loop done
+    dma_lists(c + 2); // (behind the last wait for the tensor, in front of the gather: see above)
+    PMG_CHAIN_GATHER(pn, (c + 1) % 3, nxt)
+    PMG_CSTAMP(3); // next patch's values requested
+    lds_barrier(); // #1: the sums of patch c are complete
+    PMG_CSTAMP(4); // behind barrier #1
+    // the next patch first (its values have been in flight since the wavefront left the cell loop), then the stores:
+    // nothing of this iteration waits behind them
+    PMG_CHAIN_INIT(nxt, Mn)
+    PMG_CSTAMP(5); // next patch's values in LDS
+    {
+      bool bc_row = false;
+#pragma unroll
+      for (int k = 0; k < ITER; ++k)
+      {
+        const int i = t + k * THREADS;
+        const uint32_t mk = sm[(c % 3) * LCAP + (i < LCAP ? i : t)];
+        const bool mine = i < M;
+        if (mine && !(mk & (CD_BC | CD_SKIP)))
+        {
+          const double v = sy[cur * MAXM + i];
+          if constexpr (NT)
+            __builtin_nontemporal_store(v, &y[mk & CD_MASK]);
+          else
+            y[mk & CD_MASK] = v;
+        }
+        bc_row |= mine && (mk & CD_BCFIRST);
+      }
+      if (__builtin_amdgcn_ballot_w64(bc_row) != 0) // wave-uniform: interior patches never enter
+      {
+#pragma unroll
+        for (int k = 0; k < ITER; ++k)
+        {
+          const int i = t + k * THREADS;
+          const uint32_t mk = sm[(c % 3) * LCAP + (i < LCAP ? i : t)];
+          if (i < M && (mk & CD_BCFIRST))
+            y[mk & CD_MASK] = x[mk & CD_MASK]; // :273-274
+        }
+      }
+    }
+    PMG_CSTAMP(6); // stores issued
+    lds_barrier(); // #2: patch c + 1 is in LDS; the buffers of patch c are free
+    p = pn;
+    M = Mn;
+  }
+  PMG_STAMP_FLUSH(NW); // 7: end of the chain, stores acknowledged
+#undef PMG_CHAIN_GATHER
+#undef PMG_CHAIN_INIT
+#undef PMG_CSTAMP
+}
+
 __global__ void zero_list_kernel(int n, const int32_t* __restrict__ idx, double* __restrict__ y)
 {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -1699,6 +2051,32 @@ static int launch_patches(pmg_laplacian op, const double* x, double* y, int firs
   }
 }
 
+// the interior of one application as chains: one launch per chain colour (stiffness_chain_kernel)
+static int launch_chains(pmg_laplacian op, const double* x, double* y, hipStream_t s)
+{
+  if constexpr (chain_form(4))
+  {
+    if (op->P != 4)
+      return fail(PMG_ERR_INVALID, "internal: chain form at degree %d", op->P);
+    const bool nt = op->stream_policy;
+    for (size_t c = 0; c < op->chain_count.size(); ++c)
+    {
+      if (op->chain_count[c] <= 0)
+        continue;
+      if (nt)
+        stiffness_chain_kernel<4, true><<<op->chain_count[c], ChainShape<4>::THREADS, 0, s>>>(
+            x, y, op->G, op->poff, op->cdofs, op->ccar, op->lmap_id, op->lmaps, op->pcell, op->pncell, op->kappa, op->D,
+            op->chain_off, op->chain_patch, op->chain_first[c]);
+      else
+        stiffness_chain_kernel<4, false><<<op->chain_count[c], ChainShape<4>::THREADS, 0, s>>>(
+            x, y, op->G, op->poff, op->cdofs, op->ccar, op->lmap_id, op->lmaps, op->pcell, op->pncell, op->kappa, op->D,
+            op->chain_off, op->chain_patch, op->chain_first[c]);
+      op->launches++;
+    }
+  }
+  return PMG_OK;
+}
+
 // launches [l0, l1) of the plan, in stream order
 int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, hipStream_t s)
 {
@@ -1725,6 +2103,16 @@ int run_launches(pmg_laplacian op, const double* x, double* y, int l0, int l1, h
     PMG_HIP(hipStreamWaitEvent(op->stream2, op->ev_fork, 0));
   }
   int issued = 0;
+  // the interior as chains: one launch per chain colour instead of the patch colours (the whole interior or nothing;
+  // the stored tensor, resident)
+  const bool chain = op->chain_on && l0 == 0 && l1 >= op->n_launch_l && op->n_launch_l > 0 && !two
+                     && op->batch_patches == 0 && op->geometry_mode == 0;
+  if (chain)
+  {
+    PMG_TRY(launch_chains(op, x, y, s));
+    issued += (int)op->chain_count.size();
+    l0 = op->n_launch_l;
+  }
   auto join = [&]() -> int {
     PMG_HIP(hipEventRecord(op->ev_join, op->stream2));
     PMG_HIP(hipStreamWaitEvent(s, op->ev_join, 0));
@@ -1831,7 +2219,8 @@ long long laplacian_capture_state(pmg_laplacian op)
 {
   if (op->profiling)
     return -1;
-  return ((long long)op->geometry_mode << 40) ^ ((long long)op->batch_patches << 8) ^ (long long)(op->have_diag ? 1 : 0);
+  return ((long long)op->geometry_mode << 40) ^ ((long long)op->batch_patches << 8) ^ (long long)(op->have_diag ? 1 : 0)
+         ^ (long long)(op->chain_on ? 2 : 0);
 }
 
 PatchView laplacian_patches(pmg_laplacian op)
@@ -2048,6 +2437,7 @@ extern "C" int pmg_laplacian_create_ordered(
 
   // ---- patches (host): needs the dofmap, the Dirichlet marker and cell centroids ----
   PatchPlan plan;
+  ChainPlan cplan;
   {
     std::vector<int32_t> h_dofmap((size_t)ncells * N), h_gd((size_t)ncells * 8);
     std::vector<int8_t> h_bc(total);
@@ -2099,6 +2489,20 @@ extern "C" int pmg_laplacian_create_ordered(
           op->all_affine = false;
       }
     }
+    // chain form of the interior launches (stiffness_chain_kernel).  PMG_CHAIN=0 never, =1 where a colour's chains
+    // fill the GPU (one workgroup per chain and compute unit), =2 whenever chains exist (tests on small meshes).
+    if (chain_form(degree) && (unsigned long long)plan.npatch * (unsigned long long)gpatch(nd, op->K) < (1ull << 32))
+    {
+      const char* e = std::getenv("PMG_CHAIN");
+      const int mode = e ? std::atoi(e) : PMG_CHAIN_DEFAULT;
+      if (mode > 0)
+      {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess)
+          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        PMG_TRY(build_chain_plan(cplan, plan, total, h_bc.data(), centroid.data(), mode >= 2 ? 1 : (cus * 3) / 4));
+      }
+    }
     // is every local dof written by some patch?  (else out must be zero-filled first)
     std::vector<char> touched(total, 0);
     for (uint32_t v : plan.pdofs)
@@ -2133,6 +2537,16 @@ extern "C" int pmg_laplacian_create_ordered(
   PMG_TRY(upload(&op->pdofs, plan.pdofs.data(), plan.pdofs.size(), s));
   PMG_TRY(upload(&op->lmap_id, plan.lmap_id.data(), plan.lmap_id.size(), s));
   PMG_TRY(upload(&op->lmaps, plan.lmaps.data(), plan.lmaps.size(), s));
+  if (cplan.ok)
+  {
+    PMG_TRY(upload(&op->cdofs, cplan.cdofs.data(), cplan.cdofs.size(), s));
+    PMG_TRY(upload(&op->ccar, cplan.ccar.data(), cplan.ccar.size(), s));
+    PMG_TRY(upload(&op->chain_off, cplan.chain_off.data(), cplan.chain_off.size(), s));
+    PMG_TRY(upload(&op->chain_patch, cplan.chain_patch.data(), cplan.chain_patch.size(), s));
+    op->chain_first = cplan.launch_first;
+    op->chain_count = cplan.launch_count;
+    op->chain_ok = op->chain_on = true;
+  }
 
   const long long nslots = (long long)plan.npatch * op->K;
   const long long nq_total = nslots * N;
@@ -2204,6 +2618,10 @@ extern "C" int pmg_laplacian_destroy(pmg_laplacian op)
   (void)hipFree(op->pdofs);
   (void)hipFree(op->lmap_id);
   (void)hipFree(op->lmaps);
+  (void)hipFree(op->cdofs);
+  (void)hipFree(op->ccar);
+  (void)hipFree(op->chain_off);
+  (void)hipFree(op->chain_patch);
   (void)hipFree(op->diag_inv);
   for (hipEvent_t e : op->prof_events)
     (void)hipEventDestroy(e);
@@ -2414,9 +2832,26 @@ extern "C" int pmg_laplacian_launches_per_apply(pmg_laplacian op)
   if (!op)
     return -1;
   int n = 0;
-  for (int32_t c : op->launch_count)
-    n += c > 0;
+  const bool chain = op->chain_on && op->batch_patches == 0 && op->geometry_mode == 0 && op->launch_stream.empty();
+  for (size_t l = chain ? (size_t)op->n_launch_l : 0; l < op->launch_count.size(); ++l)
+    n += op->launch_count[l] > 0;
+  if (chain)
+    for (int32_t c : op->chain_count)
+      n += c > 0;
   return n;
+}
+
+// Chain form of the interior launches (stiffness_chain_kernel): 1 = in use, 0 = not; set: PMG_ERR_INVALID if the
+// operator has no chains (small or merged level, no tensor grid of patches, another degree).
+extern "C" int pmg_laplacian_chain_form(pmg_laplacian op) { return !op ? -1 : op->chain_on ? 1 : 0; }
+extern "C" int pmg_laplacian_chain_available(pmg_laplacian op) { return !op ? -1 : op->chain_ok ? 1 : 0; }
+extern "C" int pmg_laplacian_set_chain_form(pmg_laplacian op, int on)
+{
+  PMG_REQUIRE(op, "pmg_laplacian_set_chain_form: NULL argument");
+  if (on && !op->chain_ok)
+    return fail(PMG_ERR_INVALID, "pmg_laplacian_set_chain_form: the operator has no chains of patches");
+  op->chain_on = on != 0;
+  return PMG_OK;
 }
 
 // 2 if the interior launches of an application run as two halves on two streams, else 1

@@ -509,6 +509,195 @@ int build_patch_plan(PatchPlan& plan, int P, int32_t ncells, const int32_t* dofm
   }
   return PMG_OK;
 }
+
+// ---- chains of interior patches (patches.hpp, ChainPlan) ----
+int build_chain_plan(ChainPlan& cp, const PatchPlan& plan, int32_t ndofs, const int8_t* bc, const float* centroid,
+                     int min_chains)
+{
+  cp = ChainPlan();
+  const int K = plan.K;
+  // only a level whose interior colours are launched one by one (a merged small level has nothing to gain)
+  if (plan.n_plain <= 1 || plan.n_plain != plan.n_launch_l || !plan.launch_stream.empty())
+    return PMG_OK;
+  int npi = 0; // interior patches: the first npi of the plan
+  for (int l = 0; l < plan.n_launch_l; ++l)
+    npi += plan.launch_count[l];
+  if (npi < 2 || (uint32_t)ndofs > CD_MASK || plan.max_M >= (int)CC_NONE)
+    return PMG_OK;
+
+  // patch positions: rank transform of the patch centroids; a tensor grid of patches is required
+  std::vector<float> pc[3];
+  for (int a = 0; a < 3; ++a)
+    pc[a].resize(npi);
+  for (int p = 0; p < npi; ++p)
+  {
+    double v[3] = {0, 0, 0};
+    int n = 0;
+    for (int s = 0; s < K; ++s)
+    {
+      const int32_t c = plan.pcell[(size_t)p * K + s];
+      if (c < 0)
+        continue;
+      for (int a = 0; a < 3; ++a)
+        v[a] += centroid[3 * (size_t)c + a];
+      ++n;
+    }
+    for (int a = 0; a < 3; ++a)
+      pc[a][p] = (float)(v[a] / std::max(n, 1));
+  }
+  std::vector<int32_t> gi[3];
+  int ng[3];
+  for (int a = 0; a < 3; ++a)
+  {
+    const auto mm = std::minmax_element(pc[a].begin(), pc[a].end());
+    const float ext = std::max(*mm.second - *mm.first, 1e-30f);
+    ng[a] = rank_axis(pc[a], 1e-4f * ext, gi[a]);
+  }
+  if ((long long)ng[0] * ng[1] * ng[2] != npi)
+    return PMG_OK;
+  // the chain axis: the one with the fewest positions (ties: z, then y)
+  int ax = 2;
+  for (int a = 1; a >= 0; --a)
+    if (ng[a] < ng[ax])
+      ax = a;
+  const int o1 = ax == 0 ? 1 : 0, o2 = ax == 2 ? 1 : 2;
+  const int nchain = ng[o1] * ng[o2], len = ng[ax];
+  std::vector<int32_t> grid((size_t)npi, -1); // [chain][position] -> patch
+  for (int p = 0; p < npi; ++p)
+  {
+    const size_t at = ((size_t)gi[o1][p] * ng[o2] + gi[o2][p]) * len + gi[ax][p];
+    if (grid[at] >= 0)
+      return PMG_OK; // two patches at one grid position: not a tensor grid
+    grid[at] = p;
+  }
+
+  // colour the chains (greedy, as for patches) and check that only CONSECUTIVE patches of a chain share dofs
+  std::vector<int> colour(nchain, 0);
+  int ncol = 0;
+  {
+    std::vector<uint64_t> mask(ndofs, 0);
+    std::vector<int32_t> stamp(ndofs, -1), last(ndofs, 0);
+    for (int ch = 0; ch < nchain; ++ch)
+    {
+      uint64_t used = 0;
+      for (int c = 0; c < len; ++c)
+      {
+        const int p = grid[(size_t)ch * len + c];
+        for (int i = plan.poff[p]; i < plan.poff[p + 1]; ++i)
+        {
+          const int32_t d = (int32_t)(plan.pdofs[i] & PD_MASK);
+          if (stamp[d] == ch)
+          {
+            if (last[d] < c - 1)
+              return PMG_OK; // shared by two patches that are not neighbours in the chain
+          }
+          else
+          {
+            used |= mask[d];
+            stamp[d] = ch;
+          }
+          last[d] = c;
+        }
+      }
+      int col = 0;
+      while (col < 64 && (used >> col) & 1)
+        ++col;
+      if (col >= 64)
+        return PMG_OK;
+      colour[ch] = col;
+      ncol = std::max(ncol, col + 1);
+      for (int c = 0; c < len; ++c)
+      {
+        const int p = grid[(size_t)ch * len + c];
+        for (int i = plan.poff[p]; i < plan.poff[p + 1]; ++i)
+          mask[plan.pdofs[i] & PD_MASK] |= (uint64_t)1 << col;
+      }
+    }
+  }
+  std::vector<int32_t> count(ncol, 0);
+  for (int ch = 0; ch < nchain; ++ch)
+    count[colour[ch]]++;
+  for (int c = 0; c < ncol; ++c)
+    if (count[c] < min_chains)
+      return PMG_OK; // one workgroup per chain would leave the GPU partly idle
+  // (fewer launches than the patch colours, or the form has no point)
+  if (ncol >= plan.n_plain)
+    return PMG_OK;
+
+  // first colour that touches each dof
+  std::vector<int32_t> first(ndofs, INT32_MAX);
+  for (int ch = 0; ch < nchain; ++ch)
+    for (int c = 0; c < len; ++c)
+    {
+      const int p = grid[(size_t)ch * len + c];
+      for (int i = plan.poff[p]; i < plan.poff[p + 1]; ++i)
+      {
+        int32_t& f = first[plan.pdofs[i] & PD_MASK];
+        f = std::min(f, (int32_t)colour[ch]);
+      }
+    }
+
+  // the lists
+  cp.cdofs.assign(plan.pdofs.size(), 0);
+  cp.ccar.assign(plan.pdofs.size(), CC_NONE);
+  for (int ch = 0; ch < nchain; ++ch)
+    for (int c = 0; c < len; ++c)
+    {
+      const int p = grid[(size_t)ch * len + c];
+      const int prev = c > 0 ? grid[(size_t)ch * len + c - 1] : -1;
+      const int next = c + 1 < len ? grid[(size_t)ch * len + c + 1] : -1;
+      // the patch lists are sorted by dof: two-pointer walks against the neighbours' lists
+      int ip = prev >= 0 ? plan.poff[prev] : 0, ipe = prev >= 0 ? plan.poff[prev + 1] : 0;
+      int in = next >= 0 ? plan.poff[next] : 0, ine = next >= 0 ? plan.poff[next + 1] : 0;
+      for (int i = plan.poff[p]; i < plan.poff[p + 1]; ++i)
+      {
+        const uint32_t d = plan.pdofs[i] & PD_MASK;
+        while (ip < ipe && (plan.pdofs[ip] & PD_MASK) < d)
+          ++ip;
+        while (in < ine && (plan.pdofs[in] & PD_MASK) < d)
+          ++in;
+        const bool in_prev = ip < ipe && (plan.pdofs[ip] & PD_MASK) == d;
+        const bool in_next = in < ine && (plan.pdofs[in] & PD_MASK) == d;
+        uint32_t v = d, w = CC_NONE;
+        if (bc[d])
+        {
+          v |= CD_BC;
+          if (first[d] == colour[ch] && !in_prev)
+            v |= CD_BCFIRST;
+        }
+        else
+        {
+          if (in_next)
+            v |= CD_SKIP;
+          if (in_prev)
+            w = (uint32_t)(ip - plan.poff[prev]);
+          else if (first[d] < colour[ch])
+            w |= CC_ACC;
+        }
+        cp.cdofs[i] = v;
+        cp.ccar[i] = w;
+      }
+    }
+
+  // chains in colour order
+  std::vector<int32_t> order(nchain);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return colour[a] < colour[b]; });
+  cp.chain_off.assign(nchain + 1, 0);
+  cp.chain_patch.reserve(npi);
+  for (int i = 0; i < nchain; ++i)
+  {
+    for (int c = 0; c < len; ++c)
+      cp.chain_patch.push_back(grid[(size_t)order[i] * len + c]);
+    cp.chain_off[i + 1] = (int32_t)cp.chain_patch.size();
+  }
+  cp.launch_count = count;
+  cp.launch_first.assign(ncol, 0);
+  for (int c = 1; c < ncol; ++c)
+    cp.launch_first[c] = cp.launch_first[c - 1] + count[c - 1];
+  cp.ok = true;
+  return PMG_OK;
+}
 } // namespace pmg
 
 extern "C" int pmg_set_merge_threshold(long long patch_dofs)

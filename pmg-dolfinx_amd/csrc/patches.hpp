@@ -155,6 +155,33 @@ struct PatchView
   long long npdofs = 0; // total entries of pdofs
 };
 
+// Chains (round 4, second half): the interior patches of a large level strung together along the axis with the fewest
+// patch positions (z on a box whose patches are long in z), one PERSISTENT workgroup per chain (stiffness_chain_kernel,
+// laplacian.hip).  A chain is walked in order, so the dofs two consecutive patches share never pass through global
+// memory: the later patch starts its accumulator from the earlier one's LDS sums ("carry") and the earlier one does not
+// store them ("skip").  Chains are coloured like patches (no two chains of a colour share a dof): on a tensor grid FOUR
+// launches instead of eight, each workgroup alive for a whole column of patches, the gather of patch c + 1 and the
+// write-back of patch c - 1 under the cell loop of patch c.
+// Lists parallel to PatchPlan::pdofs (same offsets; only the interior patches' entries are filled):
+//   cdofs: dof | CD_BC | CD_SKIP | CD_BCFIRST        ccar: position of the dof in the previous patch of the chain
+//   (CC_NONE = none) | CC_ACC (an earlier LAUNCH touched the dof and no carry brings its sum: read y)
+constexpr uint32_t CD_BC = 0x80000000u;      // Dirichlet dof
+constexpr uint32_t CD_SKIP = 0x40000000u;    // the next patch of the chain carries this dof on: no store
+constexpr uint32_t CD_BCFIRST = 0x20000000u; // Dirichlet dof whose row y = x this entry writes (exactly one per dof)
+constexpr uint32_t CD_MASK = 0x1fffffffu;
+constexpr uint32_t CC_ACC = 0x80000000u;
+constexpr uint32_t CC_NONE = 0xffffu;
+struct ChainPlan
+{
+  bool ok = false; // false: the level keeps its coloured patch launches (no tensor grid of patches, too few chains ...)
+  std::vector<uint32_t> cdofs, ccar;
+  std::vector<int32_t> chain_off, chain_patch; // patches of chain i: chain_patch[chain_off[i] .. chain_off[i + 1])
+  std::vector<int32_t> launch_first, launch_count; // chains of each colour, in stream order
+};
+// min_chains: a colour with fewer chains than this cannot fill the GPU with one workgroup per chain -> not ok
+int build_chain_plan(ChainPlan& cp, const PatchPlan& plan, int32_t ndofs, const int8_t* bc, const float* centroid,
+                     int min_chains);
+
 // Build the plan.  `centroid` [ncells*3] drives the grouping (tensor-grid blocks
 // when the centroids form a tensor grid, Morton-ordered chunks otherwise);
 // correctness does not depend on the grouping, only the amount of sharing does.

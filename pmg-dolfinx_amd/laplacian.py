@@ -161,6 +161,16 @@ class MatFreeLaplacian:
         """2 if the interior colour launches run as two halves on two streams (include/pmg_amd.h), else 1."""
         return call("pmg_laplacian_apply_streams", self._handle)
 
+    def chain_available(self) -> bool:
+        """Has the operator chains of patches (include/pmg_amd.h, "Chain form")?"""
+        return bool(call("pmg_laplacian_chain_available", self._handle))
+
+    def chain_form(self) -> bool:
+        return bool(call("pmg_laplacian_chain_form", self._handle))
+
+    def set_chain_form(self, on: bool):
+        call("pmg_laplacian_set_chain_form", self._handle, 1 if on else 0)
+
     def time_kernel(self, x: Vector, y: Vector, reps: int) -> float:
         """Mean milliseconds of one stiffness-kernel launch (one patch colour);
         an operator application issues ``launches_per_apply()`` of them (HIP

@@ -837,3 +837,76 @@ def test_two_stream_halves_agree_with_oracle(pm, P, n, shuffle, monkeypatch):
     op.get_diag_inverse(d2)
     one.get_diag_inverse(d1)
     assert _relerr(d2.data_copy(), d1.data_copy()) < 1e-13
+
+
+# the interior of a large degree-4 level as chains of patches, one persistent workgroup per chain (include/pmg_amd.h,
+# "Chain form"); PMG_CHAIN=2 builds the chains on the small meshes a test can check against the oracle
+@pytest.mark.parametrize("n,wf,bc", [((4, 4, 64), None, True),      # z-chains of eight full patches
+                                    ((8, 6, 32), "stretch", True),  # the y axis has the fewest patches: chains along y
+                                    ((6, 12, 16), "stretch", False),
+                                    ((4, 4, 19), None, True),       # patches cut short (28 and 24 cells), chains of three
+                                    ((5, 3, 19), None, True),       # thin blocks folded together: no grid of patches
+                                    ((2, 2, 40), "twist", True),    # one column, trilinear cells
+                                    ((8, 8, 8), None, True)])       # chains of ONE patch (eight colours: not taken)
+def test_chain_form_agrees_with_oracle(pm, n, wf, bc, monkeypatch):
+    """Degree 4: the chain form of the interior launches gives the oracle's vector -- twice in a row (nothing carries
+    over in y or in the workgroup's buffers), equal to the patch launches to rounding, under a stream capture as well,
+    with Dirichlet rows (y = x) written once."""
+    from oracle import c_oracle as co
+
+    P = 4
+    warpf = {None: None, "stretch": (lambda x: x + 0.05 * np.sin(2.0 * np.pi * x)), "twist": twist}[wf]
+    part = pm.BoxPartition(n, warp=warpf)
+    lv = part.level(P)
+    bcm = lv.bc_marker if bc else np.zeros_like(lv.bc_marker)
+    layout = pm.make_layout(lv)
+    A = co.CLevel(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, bcm)
+    u = np.random.default_rng(23).standard_normal(lv.ndofs)
+    x = _vec(pm, layout, u)
+    ref = A.apply(u)
+    monkeypatch.setenv("PMG_CHAIN", "2")
+    try:
+        pm.set_merge_threshold(0)
+        op = pm.MatFreeLaplacian(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells, bcm, layout)
+    finally:
+        pm.set_merge_threshold(-1)
+    if n in ((8, 8, 8), (5, 3, 19)) or wf == "twist":
+        # a 4 x 4 x 1 grid of patches strung along z gives chains of one patch in eight colours -- no fewer launches
+        # than the patch colours, so the level keeps those; the twisted mesh's patches are Morton chunks
+        if not op.chain_available():
+            with pytest.raises(pm._lib.PmgError):
+                op.set_chain_form(True)
+            return
+    assert op.chain_available() and op.chain_form()
+    colours = op.launches_per_apply()
+    assert colours <= 4
+    y = pm.Vector(layout)
+    for rep in range(3):
+        y.set(float(rep) - 1.0)
+        op(x, y)
+        assert _relerr(y.data_copy(), ref) < 1e-12, rep
+    chained = y.data_copy()
+    op.set_chain_form(False)
+    assert op.launches_per_apply() >= 8
+    y.set(3.0)
+    op(x, y)
+    assert _relerr(y.data_copy(), ref) < 1e-12
+    assert _relerr(chained, y.data_copy()) < 1e-13
+    op.set_chain_form(True)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        op(x, y)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            op(x, y)
+        y.set(5.0)
+        g.replay()
+        g.replay()
+    torch.cuda.synchronize()
+    assert _relerr(y.data_copy(), ref) < 1e-12
+    # kappa is read in every application (the caller's array may change between two)
+    op2 = pm.MatFreeLaplacian(P, 0.5, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells, bcm, layout)
+    y2 = pm.Vector(layout)
+    op2(x, y2)
+    free = ~bcm.astype(bool)
+    assert _relerr(4.0 * y2.data_copy()[free], chained[free]) < 1e-12
