@@ -517,6 +517,34 @@ __device__ int g_stamp_capacity = 0; // workgroups the buffer has room for
 #define PMG_STAMP_FLUSH(nwaves)
 #endif
 
+// ---- touching the tensor ahead of its use (round 4) ------------------------------------------
+// What a wavefront can have in flight of the tensor is what its registers hold: two layers (4.8 KB), sixteen
+// wavefronts per compute unit, ~60 KB -- and with all 256 units streaming the loaded latency is such that this
+// depth gives 4.6 - 4.9 TB/s (profiles/kernel_tuning_r04.md section 10: the same cell loop takes 5 us per patch with
+// 16 units active and 10.7 us with 256).  A TOUCH costs no register: one LDS-direct load of 4 bytes per lane, every
+// lane a different 128-byte line, into a scratch word per lane that nobody reads -- 8 KB of lines requested by one
+// instruction.  A wavefront touches the 12 KB of its NEXT item when it starts an item (and its first item in the
+// gather phase), default cache policy, so that the layer loads proper (nt) find their lines in L2 or in the
+// Infinity Cache instead of HBM.  Inline assembly (no destination register, so nothing the compiler could reuse
+// early); the counter retires in order, and a touch is no slower than the tensor loads queued behind it.
+typedef __attribute__((address_space(3))) char lds_byte_t;
+__device__ __forceinline__ void lds_touch(const void* sbase, unsigned voff, unsigned lds_byte)
+{
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_byte)
+               : "memory");
+}
+#ifndef PMG_TOUCH_MASK // bit P set = the degree-P column kernel touches ahead
+#define PMG_TOUCH_MASK 0
+#endif
+constexpr bool touch_ahead(int P) { return (PMG_TOUCH_MASK >> P) & 1; }
+#ifndef PMG_TOUCH_STRIDE
+#define PMG_TOUCH_STRIDE 128
+#endif
+
 // ---- the hot kernel, column form --------------------------------------
 //
 // One workgroup per patch, NW wavefronts.  Phase 0 / write-back as in the block
@@ -640,6 +668,27 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   const int M = poff[p + 1] - off; // 1 <= M <= MAXM
   const int table = lmap_id[p];
   const int nc = pncell[p];
+  // touch-ahead (see lds_touch): the item's tensor block is CW cells of 48 N bytes, contiguous in the default layout
+  constexpr bool TOUCH = !AFF && touch_ahead(P) && WPC == 1 && !gflat(ND) && !gdense(ND);
+  __shared__ uint32_t stouch[TOUCH ? Sh::NW * 64 : 1];
+  auto touch_item = [&](int it) {
+    if constexpr (TOUCH)
+    {
+      constexpr unsigned STRIDE = PMG_TOUCH_STRIDE; // bytes between two touched words
+      constexpr unsigned BYTES = CW * 3 * N * 16, LINES = (BYTES + STRIDE - 1) / STRIDE + 1;
+      const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+      const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_byte_t*)&stouch[w * 64]);
+      const char* base = reinterpret_cast<const char*>(G + ((size_t)p * K + (size_t)(it * CW < K ? it * CW : K - 1)) * 3 * N);
+      unsigned ln = (unsigned)(t & 63);
+      asm volatile("" : "+v"(ln)); // (opaque: nothing of the offsets is computed ahead and held through the cell loop)
+#pragma unroll
+      for (unsigned j = 0; j < (LINES + 63) / 64; ++j)
+      {
+        const unsigned o = (ln + 64 * j) * STRIDE;
+        lds_touch(base, o < BYTES ? o : BYTES - 4, dst);
+      }
+    }
+  };
 
   // ---- phase 0: gather (unconditional loads, clamped indices: counted vmcnt waits)
   {
@@ -652,6 +701,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     }
     const int cellk = pcell[(size_t)p * K + (t < K ? t : K - 1)];
     const double dval = Dg[t < ND * ND ? t : ND * ND - 1];
+    touch_item(__builtin_amdgcn_readfirstlane((t >> 6) / WPC)); // the wavefront's first item, under the gather
     double xv[ITER], yv[ITER];
 #pragma unroll
     for (int k = 0; k < ITER; ++k)
@@ -732,16 +782,22 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
 #endif
     const int slot = it * CW + cw;
     const int slotc = slot < K ? slot : K - 1;
-    const uint16_t* lm = lmaps + (size_t)table * (K * N) + (size_t)slotc * N + ab;
+    if (it + NG < items)
+      touch_item(__builtin_amdgcn_readfirstlane(it + NG)); // the wavefront's next item
+    // (scalar bases + 32-bit lane offsets: a 64-bit per-lane pointer costs two registers, and a spilled one is reloaded
+    // behind a wait that drains the memory counter)
+    const uint16_t* lmb = lmaps + (size_t)table * (K * N);
+    const unsigned lmo = (unsigned)(slotc * N + ab);
     // dense layout: the item's (layer, pair) runs of WL elements, element = the lane's (cell, column) index
     constexpr bool DENSE = !AFF && gdense(ND);
     constexpr int GPS = DENSE ? WL : NQ2; // stride between the three pairs of a layer
-    const double2* Gs = DENSE ? G + (size_t)p * gpatch(ND, K) + (size_t)(it < Sh::ITEMS ? it : Sh::ITEMS - 1) * (ND * 3 * WL) + lw
-                              : G + ((size_t)p * K + slotc) * 3 * N + ab;
+    const double2* Gb = G + (size_t)p * (DENSE ? gpatch(ND, K) : (long long)K * 3 * N);
+    const unsigned Gs = DENSE ? (unsigned)((it < Sh::ITEMS ? it : Sh::ITEMS - 1) * (ND * 3 * WL) + lw)
+                              : (unsigned)(slotc * 3 * N + ab);
     int l[ND];
 #pragma unroll
     for (int k = 0; k < ND; ++k)
-      l[k] = lm[k * NQ2];
+      l[k] = lmb[lmo + (unsigned)(k * NQ2)];
     // storedG: G layers 0 .. GD-1 in flight (empty slots hold zeros).
     // affine cells (AFF): G_q = w_a w_b w_c * Gc with one constant tensor Gc per cell.
     constexpr int GD = 1; // G layers in flight per wave (deeper costs registers, i.e. resident waves: no gain)
@@ -775,9 +831,9 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
 #pragma unroll
       for (int d = 0; d < GD; ++d)
       {
-        gq[d][0] = gload<NT>(Gs + d * 3 * GPS);
-        gq[d][1] = gload<NT>(Gs + d * 3 * GPS + GPS);
-        gq[d][2] = gload<NT>(Gs + d * 3 * GPS + 2 * GPS);
+        gq[d][0] = gload<NT>(Gb + (Gs + (unsigned)(d * 3 * GPS)));
+        gq[d][1] = gload<NT>(Gb + (Gs + (unsigned)(d * 3 * GPS + GPS)));
+        gq[d][2] = gload<NT>(Gb + (Gs + (unsigned)(d * 3 * GPS + 2 * GPS)));
       }
     }
     const double kap = skap[slotc];
@@ -823,9 +879,9 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
         g45 = gq[k % GD][2];
         if (k + GD < ND) // refill the slot with layer k + GD
         {
-          gq[k % GD][0] = gload<NT>(Gs + (k + GD) * 3 * GPS);
-          gq[k % GD][1] = gload<NT>(Gs + (k + GD) * 3 * GPS + GPS);
-          gq[k % GD][2] = gload<NT>(Gs + (k + GD) * 3 * GPS + 2 * GPS);
+          gq[k % GD][0] = gload<NT>(Gb + (Gs + (unsigned)((k + GD) * 3 * GPS)));
+          gq[k % GD][1] = gload<NT>(Gb + (Gs + (unsigned)((k + GD) * 3 * GPS + GPS)));
+          gq[k % GD][2] = gload<NT>(Gb + (Gs + (unsigned)((k + GD) * 3 * GPS + 2 * GPS)));
         }
       }
       q_s[ab] = u[k];

@@ -1,7 +1,8 @@
 """Where a wavefront of the chain kernel spends its time: run a library built with -DPMG_STAMPS
 (tools/build_variant.sh stamps -DPMG_STAMPS) and summarise the clock readings of every chain's MIDDLE patch.
 
-usage: PMG_AMD_LIB=tools/abl/lib_stamps.so PMG_CHAIN=1 python tools/stamp_chain.py [n]
+usage: PMG_AMD_LIB=tools/abl/lib_stamps.so PMG_CHAIN=1 python tools/stamp_chain.py [n | nx,ny,nz]
+(PMG_CHAIN=2 for meshes with fewer chains per colour than compute units: how does a unit stream when the others idle?)
 
 Stamps (10 ns ticks): 0 kernel entry, 1 top of the middle patch, 2 its cell loop done, 3 next patch's values requested,
 4 behind barrier #1, 5 next patch's values in LDS, 6 stores issued, 7 end of the chain (stores acknowledged)."""
@@ -17,11 +18,14 @@ os.environ.setdefault("PMG_AMD_LIB_ALLOW_MISSING", "1")
 os.environ.setdefault("PMG_CHAIN", "1")
 import pmg_dolfinx_amd as pm
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+n = sys.argv[1] if len(sys.argv) > 1 else "64"
+n = tuple(int(v) for v in n.split(",")) if "," in n else int(n)
 P = 4
 part = pm.BoxPartition(n)
 lv = part.level(P)
 layout = pm.make_layout(lv)
+if os.environ.get("PMG_CHAIN") == "2":
+    pm.set_merge_threshold(0)  # coloured launches on small meshes too
 op = pm.MatFreeLaplacian(P, 2.0, lv.dofmap, part.xgeom, part.geom_dofmap, lv.lcells, lv.bcells, lv.bc_marker, layout)
 assert op.chain_available()
 x, y = pm.Vector(layout), pm.Vector(layout)
