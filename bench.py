@@ -1045,6 +1045,35 @@ def main():
                 gbs = algorithmic_bytes_per_cell(Ps) * parts.ncells / (ms * 1e-3) / 1e9
                 sweep[f"p{Ps}"] = {**entry, "launches": ops.launches_per_apply(), "apply_ms": round(ms, 5),
                                    "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+                if Ps == 4:
+                    # the same application in its chain form (include/pmg_amd.h "Chain form"; off by default: measured
+                    # slower, profiles/kernel_tuning_r04.md section 9), checked against the patch launches' vector
+                    keep = os.environ.get("PMG_CHAIN")
+                    os.environ["PMG_CHAIN"] = "1"
+                    try:
+                        opc = pm.MatFreeLaplacian(Ps, 2.0, lvs.dofmap, parts.xgeom, parts.geom_dofmap, lvs.lcells,
+                                                  lvs.bcells, lvs.bc_marker, lays)
+                    finally:
+                        if keep is None:
+                            del os.environ["PMG_CHAIN"]
+                        else:
+                            os.environ["PMG_CHAIN"] = keep
+                    if opc.chain_available():
+                        yc = pm.Vector(lays)
+                        opc(us, yc)
+                        torch.cuda.synchronize()
+                        errc = float((yc.data - ys.data).abs().max() / ys.data.abs().max())
+                        opc.time_kernel(us, yc, 3)
+                        msc = opc.time_kernel(us, yc, args.kernel_reps) * opc.launches_per_apply()
+                        gbc = algorithmic_bytes_per_cell(Ps) * parts.ncells / (msc * 1e-3) / 1e9
+                        sweep["p4"]["chain_form"] = {
+                            "launches": opc.launches_per_apply(), "apply_ms": round(msc, 5), "achieved": round(gbc, 1),
+                            "frac": round(gbc / HBM_PEAK_GBS, 4), "rel_diff_vs_patch_launches": errc,
+                            "note": "one persistent workgroup per chain of patches; opt-in (PMG_CHAIN=1), not `value`"}
+                        if not errc < 1e-12:
+                            parity_failures.append(f"degree_sweep p4 chain form: rel. diff {errc:.3e}")
+                        del yc
+                    del opc
                 del ops, us, ys, lays, lvs, parts
                 torch.cuda.empty_cache()
             out["degree_sweep"] = {"note": "operator apply only (back-to-back replays of the colour launches), model storedG, "
