@@ -622,6 +622,31 @@ constexpr bool stream_form(int P)
 {
   return ((PMG_STREAM_MASK >> P) & 1) && Shape_wpc(P) == 1 && !gflat(P + 1);
 }
+// Issue priority by progress inside an item (experiment, -DPMG_PRIO_BALANCE=1 | 2; profiles/kernel_tuning_r04.md
+// section 11): the wavefronts of a SIMD are served in age order (section 9), so the older half of a workgroup reaches
+// the closing barrier first and idles there with nothing in flight.  =1: a wavefront early in its item ranks higher
+// (layers 3 3 2 2 1 ...), =2: one about to finish ranks higher; gather and write-back at 3 either way.
+#ifndef PMG_PRIO_BALANCE
+#define PMG_PRIO_BALANCE 0
+#endif
+__device__ __forceinline__ void prio_level(int v) // v is a constant after unrolling: one s_setprio remains
+{
+  if constexpr (PMG_PRIO_BALANCE != 0)
+  {
+    switch (v)
+    {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+  }
+}
+__device__ __forceinline__ void layer_prio(int k, int nd)
+{
+  const int early = 3 - (2 * k + 1) / nd - (k + 1 == nd ? 1 : 0); // nd = 5: 3 3 2 2 1
+  prio_level(PMG_PRIO_BALANCE == 2 ? 4 - early : early);          //          1 1 2 2 3
+}
 // minimum waves per SIMD the register allocation has to leave room for: two workgroups per CU up to
 // P = 4; the register-heavy degrees take what they need (profiles/kernel_resources_r02.md)
 template <int P>
@@ -662,6 +687,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
 
   PMG_STAMP_DECL;
   PMG_STAMP(0); // entry
+  prio_level(3);
   const int p = first + blockIdx.x;
   const int t = threadIdx.x;
   const int off = poff[p];
@@ -884,6 +910,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
           gq[k % GD][2] = gload<NT>(Gb + (Gs + (unsigned)((k + GD) * 3 * GPS + 2 * GPS)));
         }
       }
+      layer_prio(k, ND);
       q_s[ab] = u[k];
       slice_sync();
       double qr = 0.0, qs = 0.0, qt = 0.0;
@@ -955,6 +982,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     // (the thread index made opaque here: otherwise the list addresses are computed ahead of the cell loop and
     // held -- or spilled -- through it)
     PMG_STAMP(4); // cell loop done
+    prio_level(3);
     int tw = t;
     asm volatile("" : "+v"(tw));
     uint32_t mk[ITER];
