@@ -1014,3 +1014,97 @@ def test_a_halo_window_wait_is_bounded(built):
     (out,) = _run_ranks(_window_timeout_worker, 1, ())
     assert 0.15 < out["seconds"] < 5.0, out
     assert "did not arrive within the time limit" in out["error"], out
+
+
+def _stretch(x):
+    """A separable stretch: cell centroids stay on a tensor grid (tensor-block patches, chains of patches)."""
+    return x + 0.05 * np.sin(2.0 * np.pi * x)
+
+
+def test_chain_form_between_two_ranks_as_threads(built, monkeypatch):
+    """The chain form of the degree-4 interior launches (include/pmg_amd.h "Chain form") inside a distributed
+    application: halo begin, the interior as chains, halo end, the boundary shell as one atomic launch -- two ranks
+    as threads, apply and two V-cycles against the single-domain oracle."""
+    import threading
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import pmg_dolfinx_amd as pm
+    from oracle import pmg_oracle as po
+
+    n, dims, orders, world, k = (12, 4, 32), (2, 1, 1), (2, 4), 2, 3
+    monkeypatch.setenv("PMG_CHAIN", "2")
+    W = _ThreadWorld(world)
+    res, errors = [None] * world, []
+    gm = po.BoxMesh(n, warp=_stretch)
+    A = po.Laplacian(4, 2.0, gm.dofmap(4), gm.xgeom, gm.geom_dofmap, gm.boundary_marker(4))
+    ug = np.random.default_rng(3).standard_normal(A.ndofs)
+    Aug = A.apply(ug)
+    mesh, ops, sm, it, mg, b, eigs = po.build_hierarchy(n, orders, cheb_its=k, warp=_stretch)
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                H = pm.PoissonHierarchy(n, orders, kappa=2.0, cheb_its=k, proc_dims=dims, rank=rank, size=world,
+                                        warp=_stretch, comm=_ThreadComm(W, rank))
+                lv, layout, op = H.levels[-1], H.layouts[-1], H.operators[-1]
+                x, y = pm.Vector(layout), pm.Vector(layout)
+                xl = np.zeros(lv.ndofs)
+                xl[: lv.size_local] = ug[lv.local_to_global[: lv.size_local]]
+                x.data.copy_(torch.from_numpy(xl))
+                errs = []
+                for form in (True, False):
+                    if op.chain_available():
+                        op.set_chain_form(form)
+                    y.set(9.0)
+                    op(x, y)
+                    ref = Aug[lv.local_to_global[: lv.size_local]]
+                    errs.append(float(np.abs(y.data_copy()[: lv.size_local] - ref).max() / np.abs(ref).max()))
+                if op.chain_available():
+                    op.set_chain_form(True)
+                # two V-cycles against the oracle's, with this hierarchy's smoother bounds (rank 0 runs the oracle)
+                if rank == 0:
+                    for s_, e in zip(sm, H.eig_ranges):
+                        s_.eig_range = e
+                    xo = np.zeros_like(b)
+                    shared["xo"] = []
+                    for _ in range(2):
+                        xo = mg.apply(b, xo)
+                        shared["xo"].append(xo.copy())
+                W.wait()
+                xv = H.new_vector()
+                xv.set(0.0)
+                verr = []
+                for c in range(2):
+                    H.mg.apply(H.rhs[-1], xv)
+                    ref = shared["xo"][c]
+                    verr.append(float(np.abs(xv.data_copy()[: lv.size_local] - ref[lv.local_to_global[: lv.size_local]]).max()
+                                      / np.abs(ref).max()))
+                torch.cuda.current_stream().synchronize()
+                res[rank] = {"chains": op.chain_available(), "launches": op.launches_per_apply(), "apply_err": errs,
+                             "vcycle_err": verr}
+        except BaseException:  # noqa: BLE001
+            import traceback
+
+            errors.append((rank, traceback.format_exc()))
+            W.barrier.abort()
+
+    shared = {}
+    try:
+        pm.set_merge_threshold(0)  # coloured launches on this small mesh too
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=600)
+    finally:
+        pm.set_merge_threshold(-1)
+    assert not errors, "\n".join(f"rank {r}:\n{tb}" for r, tb in errors)
+    assert all(r is not None for r in res)
+    assert any(r["chains"] for r in res), "no rank built chains: the test does not exercise the chain form"
+    for r in res:
+        assert max(r["apply_err"]) < 1e-12, r
+        assert max(r["vcycle_err"]) < 1e-10, r
