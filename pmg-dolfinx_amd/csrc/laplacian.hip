@@ -1664,7 +1664,7 @@ __global__ void __launch_bounds__(ChainShape<P>::THREADS)
   const int slotc = slot < K ? slot : K - 1;
   const int ch = first_chain + blockIdx.x;
   const int c0 = chain_off[ch], nck = chain_off[ch + 1] - c0;
-#ifdef PMG_CHAIN_PRIO // experiment: issue priority against the age order of the wavefronts on a SIMD
+#if defined(PMG_CHAIN_PRIO) && PMG_CHAIN_PRIO <= 2 // experiment: issue priority against the age order on a SIMD
   switch (PMG_CHAIN_PRIO == 1 ? wave >> 2 : 3 - (wave >> 2))
   {
   case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -1673,6 +1673,22 @@ __global__ void __launch_bounds__(ChainShape<P>::THREADS)
   default: break;
   }
 #endif
+  // PMG_CHAIN_PRIO = 3: priority by PROGRESS -- a wavefront in an earlier layer of its item outranks one in a later
+  // layer (3 2 1 0 0 ...), so whoever the age order starves catches up; everything outside the cell loop at 3
+  auto chain_prio = [](int v) {
+#if defined(PMG_CHAIN_PRIO) && PMG_CHAIN_PRIO == 3
+    switch (v)
+    {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+#else
+    (void)v;
+#endif
+  };
+  chain_prio(3);
   PMG_STAMP_DECL; // (diagnostic build: the phases of the chain's middle patch, tools/stamp_chain.py)
   PMG_STAMP(0);   // entry
 #ifdef PMG_STAMPS
@@ -1837,6 +1853,7 @@ __global__ void __launch_bounds__(ChainShape<P>::THREADS)
       for (int k = 0; k < ND; ++k)
       {
         const int s = k & 1;
+        chain_prio(k < 3 ? 3 - k : 0);
         q_s[ab] = u[k];
         wave_fence();
         double qr = 0.0, qs = 0.0, qt = 0.0;
@@ -1869,6 +1886,7 @@ __global__ void __launch_bounds__(ChainShape<P>::THREADS)
         Aq[k] += acc;
         wave_fence();
       }
+      chain_prio(3);
       const bool contributes = lane_ok && slot < nc; // lanes without a cell add an exact zero
 #pragma unroll
       for (int k = 0; k < ND; ++k)
