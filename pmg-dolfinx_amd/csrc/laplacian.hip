@@ -622,6 +622,47 @@ constexpr bool stream_form(int P)
 {
   return ((PMG_STREAM_MASK >> P) & 1) && Shape_wpc(P) == 1 && !gflat(P + 1);
 }
+// ---- the y contraction inside the wavefront (DPP row shifts) instead of through an LDS slice (round 4) ----
+// tools/dpp_probe.hip: a compute unit sustains 26.7 unit clocks per contraction of a wavefront with both directions
+// through LDS (the pipe the four SIMDs share), 25.8 with both as DPP shifts (the SIMDs' own ALUs), 18.7 with one each.
+// nd = 5 only: the five lanes (a, b = 0 .. 4) of a column group sit side by side, three groups to a 16-lane row; a
+// value moves as two v_mov_b32 dpp, lanes outside the group contribute through a zero coefficient (nine coefficient
+// registers per direction instead of five).
+// The transposed table without its registers.  For Lagrange polynomials on ANY distinct nodes D_ij = (l_j / l_i) /
+// (x_i - x_j), i != j, with the barycentric weights l, hence D_ji = -(l_i / l_j)^2 D_ij and
+//     (D^T f)_i = 2 D_ii f_i - rho_i sum_j D_ij (f_j / rho_j),       rho_i = (l_i / l_0)^2 = -D_0i / D_i0,
+// i.e. the backward contraction is the FORWARD one applied to the scaled fluxes: the five registers of D[.][a] (and
+// the nine shift coefficients a DPP direction would need for its transpose) become rho, 1 / rho and 2 D_ii.  Same
+// value to rounding (tests: 1e-12 against the oracle), not bit for bit.
+// PMG_DPP_MODE: 0 off; 1 the forward y derivative with DPP (transposed tables kept: spills, for the record); 2 both y
+// contractions with DPP, both transposes by the identity; 4 the identity alone (both directions through LDS).
+#ifndef PMG_DPP_MODE
+#define PMG_DPP_MODE 0
+#endif
+constexpr int dpp_mode(int P) { return P == 4 ? PMG_DPP_MODE : 0; }
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true); // bound_ctrl: lanes outside the row read zero
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// sum_s C[s + 4] * v(lane + s), s = -4 .. 4, inside the 16-lane row
+__device__ __forceinline__ double dpp_contract5(double v, const double (&C)[9])
+{
+  double acc = C[4] * v;
+  acc += C[0] * dpp_move<0x114>(v); // row_shr:4: the value of lane - 4
+  acc += C[1] * dpp_move<0x113>(v);
+  acc += C[2] * dpp_move<0x112>(v);
+  acc += C[3] * dpp_move<0x111>(v);
+  acc += C[5] * dpp_move<0x101>(v); // row_shl:1: the value of lane + 1
+  acc += C[6] * dpp_move<0x102>(v);
+  acc += C[7] * dpp_move<0x103>(v);
+  acc += C[8] * dpp_move<0x104>(v);
+  return acc;
+}
+
 // Issue priority by progress inside an item (experiment, -DPMG_PRIO_BALANCE=1 | 2; profiles/kernel_tuning_r04.md
 // section 11): the wavefronts of a SIMD are served in age order (section 9), so the older half of a workgroup reaches
 // the closing barrier first and idles there with nothing in flight.  =1: a wavefront early in its item ranks higher
@@ -678,7 +719,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   constexpr bool LIST_IN_LDS = list_in_lds(P);
   __shared__ uint32_t sm[LIST_IN_LDS ? MAXM : 1];
   __shared__ double sq[NG * WL];
-  __shared__ double sgr[NG * WL];
+  __shared__ double sgr[NG * WL + 1]; // (+ 1: the spare element idle lanes of the DPP layout write)
   __shared__ double sgs[NG * WL];
   // flat G layout: one layer of the item, as loaded (NJ x 64 double2), for the hand-over to the lanes
   constexpr bool FLAT = !AFF && WPC == 1 && gflat(ND);
@@ -771,8 +812,14 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   // them, so the fences inside the layer loop become workgroup barriers and every
   // wave runs the same number of items)
   const int wave = (t >> 6) / WPC, lane = (t & 63) + 64 * ((t >> 6) % WPC);
-  const bool lane_ok = lane < WL;
-  const int lw = lane_ok ? lane : WL - 1;
+  constexpr int DPPM = (ND == 5 && WPC == 1 && !FLAT) ? dpp_mode(P) : 0;
+  constexpr int DPPY = DPPM == 4 ? 0 : DPPM;          // 0 / 1 / 2: how much of the y direction goes through DPP
+  constexpr bool IDT = DPPM == 2 || DPPM == 4;        // transposes by the identity
+  // DPP layout: lane = 16 row + 5 g + b; column group 3 row + g = (cell of the item) nd + a; the 16th lane of a row
+  // and the groups past the item's columns idle on a copy of the last column (finite values under zero coefficients)
+  const int grp_ = 3 * ((t & 63) >> 4) + ((t & 15) / 5);
+  const bool lane_ok = DPPY ? ((t & 15) < 15 && grp_ < CW * ND) : lane < WL;
+  const int lw = DPPY ? (lane_ok ? grp_ * ND + ((t & 15) - 5 * ((t & 15) / 5)) : WL - 1) : (lane_ok ? lane : WL - 1);
   const int cw = lw / NQ2;          // cell of this lane inside the wave item
   const int ab = lw - cw * NQ2;     // column: a = x index, b = y index
   const int a = ab / ND, b = ab - a * ND;
@@ -788,10 +835,33 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     DTa[mm] = sD[mm * ND + a];
     DTb[mm] = sD[mm * ND + b];
   }
+  // shift coefficients of the DPP direction: Cb[s + 4] = D[b][b + s] inside the group, else 0
+  double Cb[DPPY >= 1 ? 9 : 1];
+  if constexpr (DPPY >= 1)
+  {
+#pragma unroll
+    for (int sft = -4; sft <= 4; ++sft)
+    {
+      const bool in = lane_ok && b + sft >= 0 && b + sft < ND;
+      Cb[sft + 4] = in ? sD[b * ND + (in ? b + sft : b)] : 0.0;
+    }
+  }
+  // the identity's constants (see dpp_mode): rho, 1 / rho, 2 D_ii for the lane's a and b
+  double rho_a = 1.0, irho_a = 1.0, d2a = 0.0, rho_b = 1.0, irho_b = 1.0, d2b = 0.0;
+  if constexpr (IDT)
+  {
+    rho_a = a == 0 ? 1.0 : -sD[a] / sD[a * ND];
+    rho_b = b == 0 ? 1.0 : -sD[b] / sD[b * ND];
+    irho_a = 1.0 / rho_a;
+    irho_b = 1.0 / rho_b;
+    d2a = 2.0 * sD[a * ND + a];
+    d2b = 2.0 * sD[b * ND + b];
+  }
   const double wab = AFF ? W1[a] * W1[b] : 0.0; // 1-D GLL weights of the lane's column
   double* q_s = sq + wave * WL + cw * NQ2;  // this cell's slices
   double* gr_s = sgr + wave * WL + cw * NQ2;
   double* gs_s = sgs + wave * WL + cw * NQ2;
+  double* gr_w = (DPPY != 0 && !lane_ok) ? sgr + NG * WL : gr_s + ab; // where the lane writes its x flux
   const int items = WPC > 1 ? (((nc + CW - 1) / CW + NG - 1) / NG) * NG : (nc + CW - 1) / CW;
   auto slice_sync = [] {
     if constexpr (WPC > 1)
@@ -826,7 +896,10 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
       l[k] = lmb[lmo + (unsigned)(k * NQ2)];
     // storedG: G layers 0 .. GD-1 in flight (empty slots hold zeros).
     // affine cells (AFF): G_q = w_a w_b w_c * Gc with one constant tensor Gc per cell.
-    constexpr int GD = 1; // G layers in flight per wave (deeper costs registers, i.e. resident waves: no gain)
+#ifndef PMG_GD
+#define PMG_GD 1
+#endif
+    constexpr int GD = P == 4 ? PMG_GD : 1; // G layers in flight per wave (deeper costs registers, i.e. resident waves: no gain)
     double2 gq[AFF ? 1 : GD][3];
     double2 gfl[FLAT ? NJ : 1]; // flat layout: the next layer as loaded
     // (only used when FLAT; the item index is wave-uniform: a scalar base plus 32-bit lane offsets)
@@ -862,13 +935,28 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
         gq[d][2] = gload<NT>(Gb + (Gs + (unsigned)(d * 3 * GPS + 2 * GPS)));
       }
     }
-    const double kap = skap[slotc];
+    // (identity modes: kappa multiplies the cell's INPUT once -- the operator is linear in it, same value to rounding --
+    // and the positions are held two to a register through the layer loop: the registers the DPP form is short of)
+    const double kap = IDT ? 1.0 : skap[slotc];
     double u[ND], Aq[ND];
-#pragma unroll
-    for (int k = 0; k < ND; ++k)
     {
-      u[k] = sx[l[k]];
-      Aq[k] = 0.0;
+      const double kin = IDT ? skap[slotc] : 1.0;
+#pragma unroll
+      for (int k = 0; k < ND; ++k)
+      {
+        u[k] = IDT ? kin * sx[l[k]] : sx[l[k]];
+        Aq[k] = 0.0;
+      }
+    }
+    unsigned lp[IDT ? (ND + 1) / 2 : 1];
+    if constexpr (IDT)
+    {
+#pragma unroll
+      for (int k = 0; k < ND; k += 2)
+        lp[k / 2] = (unsigned)l[k] | (k + 1 < ND ? (unsigned)l[k + 1] << 16 : 0u);
+#pragma unroll
+      for (int j = 0; j < (ND + 1) / 2; ++j)
+        asm volatile("" : "+v"(lp[j])); // (opaque: the unpacked values are not kept alongside)
     }
 #pragma unroll
     for (int k = 0; k < ND; ++k)
@@ -914,26 +1002,54 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
       q_s[ab] = u[k];
       slice_sync();
       double qr = 0.0, qs = 0.0, qt = 0.0;
+      if constexpr (DPPY >= 1)
+        qs = dpp_contract5(u[k], Cb); // d/dy inside the wavefront
 #pragma unroll
       for (int mm = 0; mm < ND; ++mm)
       {
         qr += Da[mm] * slice_load<UNPAIRED>(q_s[mm * ND + b]);  // d/dx: sum over a, :195-199
-        qs += Db[mm] * slice_load<UNPAIRED>(q_s[a * ND + mm]);  // d/dy: sum over b, :206-210
+        if constexpr (DPPY == 0)
+          qs += Db[mm] * slice_load<UNPAIRED>(q_s[a * ND + mm]);  // d/dy: sum over b, :206-210
         qt += Dg[k * ND + mm] * u[mm];    // d/dz: registers, uniform table, :214-218
       }
       const double fr = kap * (g01.x * qr + g01.y * qs + g23.x * qt); // :233
       const double fs = kap * (g01.y * qr + g23.y * qs + g45.x * qt); // :234
       const double ft = kap * (g23.x * qr + g45.x * qs + g45.y * qt); // :235
-      gr_s[ab] = fr;
-      gs_s[ab] = fs;
-      slice_sync();
       double acc = 0.0;
-#pragma unroll
-      for (int mm = 0; mm < ND; ++mm)
+      if constexpr (IDT)
       {
-        acc += DTa[mm] * slice_load<UNPAIRED>(gr_s[mm * ND + b]); // :246-251
-        acc += DTb[mm] * slice_load<UNPAIRED>(gs_s[a * ND + mm]); // :255-259
-        Aq[mm] += Dg[k * ND + mm] * ft;     // :263-267
+        // the transposes as forward contractions of the scaled fluxes (see dpp_mode)
+        // (DPP layout: an idle lane is a copy of the last column whose y derivative came from the wrong neighbours --
+        // its flux must not reach the slice the real lane writes)
+        *gr_w = fr * irho_a; // (no branch here: one costs the layer loop its register allocation)
+        if constexpr (DPPY < 2)
+          gs_s[ab] = fs * irho_b;
+        slice_sync();
+        double sx_ = 0.0, sy_ = 0.0;
+        if constexpr (DPPY >= 2)
+          sy_ = dpp_contract5(fs * irho_b, Cb); // :255-259 inside the wavefront
+#pragma unroll
+        for (int mm = 0; mm < ND; ++mm)
+        {
+          sx_ += Da[mm] * slice_load<UNPAIRED>(gr_s[mm * ND + b]); // :246-251
+          if constexpr (DPPY < 2)
+            sy_ += Db[mm] * slice_load<UNPAIRED>(gs_s[a * ND + mm]); // :255-259
+          Aq[mm] += Dg[k * ND + mm] * ft;     // :263-267
+        }
+        acc = (d2a * fr + d2b * fs) - (rho_a * sx_ + rho_b * sy_);
+      }
+      else
+      {
+        gr_s[ab] = fr;
+        gs_s[ab] = fs;
+        slice_sync();
+#pragma unroll
+        for (int mm = 0; mm < ND; ++mm)
+        {
+          acc += DTa[mm] * slice_load<UNPAIRED>(gr_s[mm * ND + b]); // :246-251
+          acc += DTb[mm] * slice_load<UNPAIRED>(gs_s[a * ND + mm]); // :255-259
+          Aq[mm] += Dg[k * ND + mm] * ft;     // :263-267
+        }
       }
       Aq[k] += acc;
       slice_sync();
@@ -945,7 +1061,10 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     const bool contributes = lane_ok && slot < nc;
 #pragma unroll
     for (int k = 0; k < ND; ++k)
-      atomicAdd(&sy[l[k]], contributes ? Aq[k] : 0.0); // :270,277 -- in LDS (ds_add_f64)
+    {
+      const int lk = IDT ? (int)((lp[k / 2] >> (16 * (k & 1))) & 0xffffu) : l[k];
+      atomicAdd(&sy[lk], contributes ? Aq[k] : 0.0); // :270,277 -- in LDS (ds_add_f64)
+    }
   }
   // ---- write back (plain stores; the accumulator started from the earlier colours' y)
 #ifdef PMG_ABL_NOWB
