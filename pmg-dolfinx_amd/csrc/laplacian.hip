@@ -640,6 +640,9 @@ constexpr bool stream_form(int P)
 #define PMG_DPP_MODE 0
 #endif
 constexpr int dpp_mode(int P) { return P == 4 ? PMG_DPP_MODE : 0; }
+#ifndef PMG_IDT_MASK // bit P set = the degree-P column kernel replaces its transposed tables by the identity
+#define PMG_IDT_MASK 0
+#endif
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v)
 {
@@ -814,7 +817,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   const int wave = (t >> 6) / WPC, lane = (t & 63) + 64 * ((t >> 6) % WPC);
   constexpr int DPPM = (ND == 5 && WPC == 1 && !FLAT) ? dpp_mode(P) : 0;
   constexpr int DPPY = DPPM == 4 ? 0 : DPPM;          // 0 / 1 / 2: how much of the y direction goes through DPP
-  constexpr bool IDT = DPPM == 2 || DPPM == 4;        // transposes by the identity
+  constexpr bool IDT = DPPM == 2 || DPPM == 4 || (((PMG_IDT_MASK) >> P) & 1); // transposes by the identity
   // DPP layout: lane = 16 row + 5 g + b; column group 3 row + g = (cell of the item) nd + a; the 16th lane of a row
   // and the groups past the item's columns idle on a copy of the last column (finite values under zero coefficients)
   const int grp_ = 3 * ((t & 63) >> 4) + ((t & 15) / 5);
