@@ -641,7 +641,13 @@ constexpr bool stream_form(int P)
 #endif
 constexpr int dpp_mode(int P) { return P == 4 ? PMG_DPP_MODE : 0; }
 #ifndef PMG_IDT_MASK // bit P set = the degree-P column kernel replaces its transposed tables by the identity
-#define PMG_IDT_MASK 0
+#define PMG_IDT_MASK 0x20
+#endif
+// P = 5 is the one degree where the identity pays: 129 registers instead of 164, and asked for four wavefronts per SIMD
+// the allocator finds 128 without a spill -- four workgroups per unit instead of three (33 KB of LDS each): 432 - 444
+// against 452 - 459 us at 51^3, 223 - 225 against 230 - 232 us at 40^3 (profiles/kernel_tuning_r04.md section 12).
+#ifndef PMG_P5_FOUR_WAVES
+#define PMG_P5_FOUR_WAVES 1
 #endif
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v)
@@ -694,7 +700,11 @@ __device__ __forceinline__ void layer_prio(int k, int nd)
 // minimum waves per SIMD the register allocation has to leave room for: two workgroups per CU up to
 // P = 4; the register-heavy degrees take what they need (profiles/kernel_resources_r02.md)
 template <int P>
-constexpr int min_waves_per_simd() { return P <= 4 ? (2 * Shape<P>::NW + 3) / 4 : 1; }
+constexpr int min_waves_per_simd()
+{
+  // (P = 5 with the identity: the allocator lands on 129 registers; asked for four wavefronts per SIMD it has to find 128)
+  return P <= 4 ? (2 * Shape<P>::NW + 3) / 4 : (P == 5 && (((PMG_IDT_MASK) >> 5) & 1) && PMG_P5_FOUR_WAVES) ? 4 : 1;
+}
 template <int P, bool AFF, bool NT>
 __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     stiffness_column_kernel(const double* __restrict__ x, double* __restrict__ y,
