@@ -639,7 +639,10 @@ constexpr bool stream_form(int P)
 #ifndef PMG_DPP_MODE
 #define PMG_DPP_MODE 0
 #endif
-constexpr int dpp_mode(int P) { return P == 4 ? PMG_DPP_MODE : 0; }
+#ifndef PMG_DPP_MASK // bit P set = mode 2 at degree P (degrees whose nd <= 8 columns groups fit a 16-lane row)
+#define PMG_DPP_MASK 0
+#endif
+constexpr int dpp_mode(int P) { return P == 4 && PMG_DPP_MODE != 0 ? PMG_DPP_MODE : (((PMG_DPP_MASK) >> P) & 1) ? 2 : 0; }
 #ifndef PMG_IDT_MASK // bit P set = the degree-P column kernel replaces its transposed tables by the identity
 #define PMG_IDT_MASK 0x20
 #endif
@@ -657,18 +660,26 @@ __device__ __forceinline__ double dpp_move(double v)
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-// sum_s C[s + 4] * v(lane + s), s = -4 .. 4, inside the 16-lane row
-__device__ __forceinline__ double dpp_contract5(double v, const double (&C)[9])
+// sum_s C[s + nd - 1] * v(lane + s), s = -(nd - 1) .. nd - 1, inside the 16-lane row
+template <int ND>
+__device__ __forceinline__ double dpp_contract(double v, const double (&C)[2 * ND - 1])
 {
-  double acc = C[4] * v;
-  acc += C[0] * dpp_move<0x114>(v); // row_shr:4: the value of lane - 4
-  acc += C[1] * dpp_move<0x113>(v);
-  acc += C[2] * dpp_move<0x112>(v);
-  acc += C[3] * dpp_move<0x111>(v);
-  acc += C[5] * dpp_move<0x101>(v); // row_shl:1: the value of lane + 1
-  acc += C[6] * dpp_move<0x102>(v);
-  acc += C[7] * dpp_move<0x103>(v);
-  acc += C[8] * dpp_move<0x104>(v);
+  static_assert(ND >= 2 && ND <= 8, "groups of nd lanes inside a 16-lane row");
+  double acc = C[ND - 1] * v;
+#define PMG_DPP_SHIFT(S)                                                                                              \
+  if constexpr (S < ND)                                                                                               \
+  {                                                                                                                   \
+    acc += C[ND - 1 - S] * dpp_move<0x110 + S>(v); /* row_shr:S: the value of lane - S */                             \
+    acc += C[ND - 1 + S] * dpp_move<0x100 + S>(v); /* row_shl:S: the value of lane + S */                             \
+  }
+  PMG_DPP_SHIFT(1)
+  PMG_DPP_SHIFT(2)
+  PMG_DPP_SHIFT(3)
+  PMG_DPP_SHIFT(4)
+  PMG_DPP_SHIFT(5)
+  PMG_DPP_SHIFT(6)
+  PMG_DPP_SHIFT(7)
+#undef PMG_DPP_SHIFT
   return acc;
 }
 
@@ -825,14 +836,16 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
   // them, so the fences inside the layer loop become workgroup barriers and every
   // wave runs the same number of items)
   const int wave = (t >> 6) / WPC, lane = (t & 63) + 64 * ((t >> 6) % WPC);
-  constexpr int DPPM = (ND == 5 && WPC == 1 && !FLAT) ? dpp_mode(P) : 0;
+  constexpr int DPPM = (ND >= 4 && ND <= 8 && WPC == 1 && !FLAT) ? dpp_mode(P) : 0;
+  constexpr int GPR = 16 / ND; // column groups per 16-lane row
   constexpr int DPPY = DPPM == 4 ? 0 : DPPM;          // 0 / 1 / 2: how much of the y direction goes through DPP
   constexpr bool IDT = DPPM == 2 || DPPM == 4 || (((PMG_IDT_MASK) >> P) & 1); // transposes by the identity
-  // DPP layout: lane = 16 row + 5 g + b; column group 3 row + g = (cell of the item) nd + a; the 16th lane of a row
-  // and the groups past the item's columns idle on a copy of the last column (finite values under zero coefficients)
-  const int grp_ = 3 * ((t & 63) >> 4) + ((t & 15) / 5);
-  const bool lane_ok = DPPY ? ((t & 15) < 15 && grp_ < CW * ND) : lane < WL;
-  const int lw = DPPY ? (lane_ok ? grp_ * ND + ((t & 15) - 5 * ((t & 15) / 5)) : WL - 1) : (lane_ok ? lane : WL - 1);
+  // DPP layout: lane = 16 row + nd g + b; column group GPR row + g = (cell of the item) nd + a; the lanes of a row past
+  // its groups and the groups past the item's columns idle on a copy of the last column (finite values under zero
+  // coefficients)
+  const int grp_ = GPR * ((t & 63) >> 4) + ((t & 15) / ND);
+  const bool lane_ok = DPPY ? ((t & 15) < GPR * ND && grp_ < CW * ND) : lane < WL;
+  const int lw = DPPY ? (lane_ok ? grp_ * ND + ((t & 15) - ND * ((t & 15) / ND)) : WL - 1) : (lane_ok ? lane : WL - 1);
   const int cw = lw / NQ2;          // cell of this lane inside the wave item
   const int ab = lw - cw * NQ2;     // column: a = x index, b = y index
   const int a = ab / ND, b = ab - a * ND;
@@ -848,15 +861,15 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
     DTa[mm] = sD[mm * ND + a];
     DTb[mm] = sD[mm * ND + b];
   }
-  // shift coefficients of the DPP direction: Cb[s + 4] = D[b][b + s] inside the group, else 0
-  double Cb[DPPY >= 1 ? 9 : 1];
+  // shift coefficients of the DPP direction: Cb[s + nd - 1] = D[b][b + s] inside the group, else 0
+  double Cb[DPPY >= 1 ? 2 * ND - 1 : 1];
   if constexpr (DPPY >= 1)
   {
 #pragma unroll
-    for (int sft = -4; sft <= 4; ++sft)
+    for (int sft = -(ND - 1); sft <= ND - 1; ++sft)
     {
       const bool in = lane_ok && b + sft >= 0 && b + sft < ND;
-      Cb[sft + 4] = in ? sD[b * ND + (in ? b + sft : b)] : 0.0;
+      Cb[sft + ND - 1] = in ? sD[b * ND + (in ? b + sft : b)] : 0.0;
     }
   }
   // the identity's constants (see dpp_mode): rho, 1 / rho, 2 D_ii for the lane's a and b
@@ -1016,7 +1029,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
       slice_sync();
       double qr = 0.0, qs = 0.0, qt = 0.0;
       if constexpr (DPPY >= 1)
-        qs = dpp_contract5(u[k], Cb); // d/dy inside the wavefront
+        qs = dpp_contract<ND>(u[k], Cb); // d/dy inside the wavefront
 #pragma unroll
       for (int mm = 0; mm < ND; ++mm)
       {
@@ -1040,7 +1053,7 @@ __global__ void __launch_bounds__(Shape<P>::WTHREADS, min_waves_per_simd<P>())
         slice_sync();
         double sx_ = 0.0, sy_ = 0.0;
         if constexpr (DPPY >= 2)
-          sy_ = dpp_contract5(fs * irho_b, Cb); // :255-259 inside the wavefront
+          sy_ = dpp_contract<ND>(fs * irho_b, Cb); // :255-259 inside the wavefront
 #pragma unroll
         for (int mm = 0; mm < ND; ++mm)
         {
